@@ -1,0 +1,111 @@
+/* molgym_hip.h -- C ABI of the MI355X (gfx950) PPO policy/value hot path.
+ *
+ * Boundary replaced (reference = gncs/molgym, all paths under /root/reference):
+ *   mg_cov_forward      <- CovariantAC.step(observations, actions) with actions given,
+ *                          molgym/agents/covariant/agent.py:209-334 (called from
+ *                          molgym/ppo.py:26), after parse_observations (:165-197) has
+ *                          been done on the host into the padded arrays taken here.
+ *   mg_cov_backward     <- autograd of loss.backward(), molgym/ppo.py:131, through the
+ *                          same step(); gradients ACCUMULATE into grad_theta exactly as
+ *                          .grad does over mini-batches (ppo.py:122-131).
+ *   mg_ppo_loss         <- compute_loss arithmetic, molgym/ppo.py:28-52 (float64 seam).
+ *   mg_gae              <- DynamicPPOBuffer.finish_path, molgym/buffer.py:74-82 +
+ *                          util.discount_cumsum, molgym/tools/util.py:72-87.
+ *   mg_adv_normalize    <- DynamicPPOBuffer.get_data, molgym/buffer.py:104-110.
+ *   mg_grad_norm_clip   <- util.compute_gradient_norm (util.py:61-69) +
+ *                          torch.nn.utils.clip_grad_norm_ (ppo.py:144).
+ *
+ * All pointers are DEVICE pointers unless a name ends in _host.  No ownership is taken.
+ * Every entry point returns 0 on success, a negative MG_E* code otherwise, and never
+ * throws; mg_last_error() gives the text.  Launches go to `stream` (a hipStream_t passed
+ * as void*), nothing synchronises the device.
+ */
+#ifndef MOLGYM_HIP_H
+#define MOLGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_EINVAL (-1)   /* unsupported / inconsistent configuration */
+#define MG_EHIP (-2)     /* HIP runtime error */
+#define MG_ENOMEM (-3)   /* workspace too small */
+
+#define MG_MAX_Z 8
+
+/* Fixed by the build (reference defaults, molgym/tools/arg_parser.py:55-60):
+ * maxl = 4, num_cg_levels = 3, num_channels_hidden = 10, num_channels_per_element = 4. */
+typedef struct mg_cov_cfg {
+  int32_t B;            /* samples in the mini-batch                                   */
+  int32_t N;            /* canvas_size                                                 */
+  int32_t Z;            /* len(zs), zs[0] == 0 is the null symbol                      */
+  int32_t zs[MG_MAX_Z]; /* atomic numbers                                              */
+  int32_t W;            /* network_width (multiple of 4)                               */
+  int32_t G;            /* num_gaussians                                               */
+  int32_t TA;           /* total real atoms in the batch  = sum_b n_b                  */
+  int32_t TE;           /* total real edges in the batch  = sum_b n_b^2                */
+  int32_t has_beta;     /* 1: ExpSO3Distribution(beta); 0: SO3Distribution             */
+  float beta;
+  float bag_scale;
+  float min_distance, max_distance;
+} mg_cov_cfg;
+
+const char* mg_last_error(void);
+int mg_abi_version(void);
+
+/* ---- parameter vector ------------------------------------------------------------- */
+/* theta is ONE flat float32 vector.  Slot order and shapes: molgym_amd/layout.py.       */
+int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params);
+/* offsets_out[i] = float offset of slot i (n_slots entries, plus the total at the end). */
+int mg_cov_param_offsets(const mg_cov_cfg* cfg, int64_t* offsets_out_host, int32_t* n_slots_host);
+
+/* ---- workspace -------------------------------------------------------------------- */
+int mg_cov_workspace_bytes(const mg_cov_cfg* cfg, size_t* bytes_host);
+/* Look up a named intermediate inside the workspace (tests only): float offset + count. */
+int mg_cov_workspace_lookup(const mg_cov_cfg* cfg, const char* name, int64_t* offset_floats_host,
+                            int64_t* count_floats_host);
+
+/* ---- forward / backward of CovariantAC.step(obs, actions) ------------------------- */
+/* pos      [B][N][3] f32, real atoms first, zero padded (covariant/tools.py:18-31)
+ * charges  [B][N] i32 atomic numbers, 0 = padding
+ * bags     [B][Z] f32
+ * actions  [B][6] f32: focus, element index, distance, ox, oy, oz (agent.py:148-154)
+ * leb      [1730][51] f32: Y_lm (25 complex, 'qm') of the Lebedev-71 points + log weight
+ * out      [3][B] f32: logp, ent, v
+ * ws       workspace of mg_cov_workspace_bytes(); keeps what backward needs.          */
+int mg_cov_forward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
+                   const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
+                   float* out, void* stream);
+/* gout [3][B] f32: dL/dlogp, dL/dent, dL/dv.  grad_theta += dL/dtheta.                 */
+int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
+                    const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
+                    const float* gout, float* grad_theta, void* stream);
+
+/* ---- PPO loss, float64 (ppo.py:28-52) --------------------------------------------- */
+/* pred [3][B] f32 (logp, ent, v); old_logp, adv, ret [B] f64.
+ * stats[6] f64: policy_loss, entropy_loss, vf_loss, total_loss, approx_kl, clip_fraction.
+ * gout [3][B] f32 = d total_loss / d pred (may be NULL).                                */
+int mg_ppo_loss(int32_t B, const float* pred, const double* old_logp, const double* adv, const double* ret,
+                double clip_ratio, double vf_coef, double entropy_coef, double* stats, float* gout,
+                void* stream);
+
+/* ---- GAE-lambda over concatenated trajectories (buffer.py:74-82) ------------------ */
+/* path_off [P+1] i32 start offsets; rew, val [T] f64; last_val [P] f64.
+ * adv[t] = discount_cumsum(delta, gamma*lam), ret[t] = discount_cumsum(rew ++ last_val, gamma)[:-1] */
+int mg_gae(int32_t num_paths, const int32_t* path_off, const double* rew, const double* val,
+           const double* last_val, double gamma, double lam, double* adv, double* ret, void* stream);
+/* adv <- (adv - mean) / std, population std, no epsilon (buffer.py:104-110).            */
+int mg_adv_normalize(int32_t T, double* adv, double* scratch2, void* stream);
+
+/* ---- gradient norm + clip (util.py:61-69, ppo.py:144) ------------------------------ */
+/* norm_out[0] = ||g||_2 (f32, device).  If max_norm > 0: g *= min(1, max_norm/(norm+1e-6)). */
+int mg_grad_norm_clip(int64_t n, float* grad, float max_norm, float* norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLGYM_HIP_H */

@@ -1,0 +1,61 @@
+"""ctypes binding of libmolgym_hip.so (C ABI: include/molgym_hip.h).
+
+The product path has no CPU fallback: if the gfx950 library is missing or fails
+to load, importing anything that computes raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmolgym_hip.so')
+MG_MAX_Z = 8
+
+
+class CovCfg(C.Structure):
+    _fields_ = [
+        ('B', C.c_int32), ('N', C.c_int32), ('Z', C.c_int32), ('zs', C.c_int32 * MG_MAX_Z), ('W', C.c_int32),
+        ('G', C.c_int32), ('TA', C.c_int32), ('TE', C.c_int32), ('has_beta', C.c_int32), ('beta', C.c_float),
+        ('bag_scale', C.c_float), ('min_distance', C.c_float), ('max_distance', C.c_float),
+    ]
+
+
+# every symbol include/molgym_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    'mg_last_error': (C.c_char_p, []),
+    'mg_abi_version': (C.c_int, []),
+    'mg_cov_num_params': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64)]),
+    'mg_cov_param_offsets': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'mg_cov_workspace_bytes': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_size_t)]),
+    'mg_cov_workspace_lookup': (C.c_int, [C.POINTER(CovCfg), C.c_char_p, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]),
+    'mg_cov_forward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
+    'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
+    'mg_gae': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
+    'mg_adv_normalize': (C.c_int, [C.c_int32, _P, _P, _P]),
+    'mg_grad_norm_clip': (C.c_int, [C.c_int64, _P, C.c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f'molgym_hip error {rc}: {lib().mg_last_error().decode()}')

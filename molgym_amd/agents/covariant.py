@@ -1,0 +1,213 @@
+"""Covariant (Cormorant) actor-critic on the gfx950 HIP kernels.
+
+Drop-in for /root/reference/molgym/agents/covariant/agent.py:20-334: same
+constructor keywords (model_util.py:26-39), same ``step(observations, actions)``
+contract (base.py:17-19).  All arithmetic of ``step`` with actions given -- the PPO
+training path, ppo.py:26 -- runs in libmolgym_hip.so through one autograd node;
+there is no eager / CPU fallback.
+"""
+import ctypes as C
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib, layout
+from ..lebedev import lebedev_table
+from ..spaces import ActionSpace, ObservationSpace, ObservationType
+from .base import AbstractActorCritic
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def parse_observations_host(observations: List[ObservationType], zs: List[int], canvas_size: int):
+    """Observation tuples -> padded numpy arrays (agent.py:165-197, covariant/tools.py:8-49 without ase):
+    null items dropped, real atoms compacted to the front in canvas order, zero padded."""
+    B = len(observations)
+    try:
+        labels = np.array([[item[0] for item in obs[0]] for obs in observations], dtype=np.int64)
+        xyz = np.array([[item[1] for item in obs[0]] for obs in observations], dtype=np.float64)
+        bags = np.array([obs[1] for obs in observations], dtype=np.float32)
+    except ValueError as exc:  # ragged input
+        raise RuntimeError(f'malformed observations: {exc}')
+    if labels.shape != (B, canvas_size) or xyz.shape != (B, canvas_size, 3):
+        raise RuntimeError(f'canvas shape {labels.shape} does not match canvas_size {canvas_size}')
+    if bags.shape != (B, len(zs)):
+        raise RuntimeError(f'bag shape {bags.shape} does not match len(zs) {len(zs)}')
+    if labels.min(initial=0) < 0 or labels.max(initial=0) >= len(zs):
+        raise RuntimeError('Invalid atomic number index in canvas')
+    charges = np.asarray(zs, dtype=np.int32)[labels]
+    real = charges > 0
+    order = np.argsort(~real, axis=1, kind='stable')
+    charges = np.take_along_axis(charges, order, axis=1)
+    xyz = np.take_along_axis(xyz, order[..., None], axis=1)
+    natoms = real.sum(axis=1)
+    xyz[~np.take_along_axis(real, order, axis=1)] = 0.0
+    return xyz.astype(np.float32), np.ascontiguousarray(charges), bags, natoms
+
+
+class _CovStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, ac, cfg, pos, charges, bags, actions):
+        lib = _lib.lib()
+        nbytes = C.c_size_t()
+        _lib.check(lib.mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=theta.device)
+        out = torch.empty(3, cfg.B, dtype=torch.float32, device=theta.device)
+        _lib.check(lib.mg_cov_forward(C.byref(cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags), _ptr(actions),
+                                      _ptr(ac.leb), _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        ctx.save_for_backward(theta, pos, charges, bags, actions, ws)
+        ctx.cfg, ctx.ac = cfg, ac
+        ac._last_ws = ws
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        theta, pos, charges, bags, actions, ws = ctx.saved_tensors
+        lib = _lib.lib()
+        grad = torch.zeros_like(theta)
+        gout = gout.contiguous()
+        _lib.check(lib.mg_cov_backward(C.byref(ctx.cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
+                                       _ptr(actions), _ptr(ctx.ac.leb), _ptr(ws), ws.numel(), _ptr(gout), _ptr(grad),
+                                       _stream()))
+        return grad, None, None, None, None, None, None
+
+
+class CovariantAC(AbstractActorCritic):
+    def __init__(
+        self,
+        observation_space: ObservationSpace,
+        action_space: ActionSpace,
+        min_max_distance: Tuple[float, float],
+        network_width: int,
+        maxl: int,
+        num_cg_levels: int,
+        num_channels_hidden: int,
+        num_channels_per_element: int,
+        num_gaussians: int,
+        bag_scale: int,
+        beta: Optional[float] = None,
+        device=None,
+    ):
+        super().__init__(observation_space, action_space)
+        if (maxl, num_cg_levels, num_channels_hidden, num_channels_per_element) != (layout.MAXL, layout.NLEV,
+                                                                                    layout.CH, layout.CE):
+            raise RuntimeError('the gfx950 kernels are built for maxl=4, num_cg_levels=3, num_channels_hidden=10, '
+                               'num_channels_per_element=4 (the reference defaults, arg_parser.py:55-60)')
+        self.device = torch.device(device) if device is not None else torch.device('cuda')
+        self.dtype = torch.float
+        self.zs = list(self.observation_space.zs)
+        self.min_distance, self.max_distance = min_max_distance
+        assert self.min_distance < self.max_distance
+        self.beta = beta
+        self.max_sh, self.num_cg_levels = maxl, num_cg_levels
+        self.num_channels_hidden, self.num_channels_per_element = num_channels_hidden, num_channels_per_element
+        self.num_gaussians, self.network_width, self.bag_scale = num_gaussians, network_width, bag_scale
+        self.num_channels_out = len(self.zs) * num_channels_per_element
+        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians)
+        self.theta = torch.nn.Parameter(self._init_theta(total))
+        self.register_buffer('leb', torch.from_numpy(lebedev_table()), persistent=False)
+        self._last_ws = None
+        self.to(self.device)
+
+    # -- parameters -----------------------------------------------------------------------------
+    def _init_theta(self, total: int) -> torch.Tensor:
+        """Same initialisers as the reference stack: torch Linear defaults for the radial / input
+        Linear layers, U(-1,1)*gain/max(dims) for the complex mixes ('rand'), orthogonal + zero bias
+        for the MLPs (modules.py:30-34), log 0.1 for the GMM widths (agent.py:134-136)."""
+        theta = torch.zeros(total)
+        for name, (off, shape) in self.slot_table.items():
+            n = int(np.prod(shape))
+            view = theta[off:off + n].view(shape)
+            if name.endswith('scales'):
+                view.copy_(torch.tensor([0., 1., 2., 3., 0., 1., 2., 3.]).view(shape))
+            elif name.endswith('phases'):
+                view.copy_(torch.tensor([0.] * 4 + [np.pi / 2] * 4).view(shape))
+            elif 'cat_mix.weights' in name:
+                gain = 1.0 if 'edge_levels' in name else 10.0
+                view.copy_((2 * torch.rand(shape) - 1) * (gain / max(shape)))
+            elif name.startswith('phi_') and name.endswith('weight'):
+                torch.nn.init.orthogonal_(view)
+            elif name.startswith('phi_') and name.endswith('bias'):
+                view.zero_()
+            elif name == 'distance_log_stds':
+                view.fill_(float(np.log(0.1)))
+            elif ('.linear.' in name or name.endswith('lin.weight')) and name.endswith('weight'):
+                lin = torch.nn.Linear(shape[1], shape[0])
+                view.copy_(lin.weight.data)
+                self._pending_bias = lin.bias.data.clone()
+            elif name.endswith('bias'):
+                view.copy_(self._pending_bias)
+            else:
+                raise RuntimeError(f'no initialiser for {name}')
+        if hasattr(self, '_pending_bias'):
+            del self._pending_bias
+        return theta
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Named tensors with the reference module's state_dict keys."""
+        t = self.theta.detach()
+        return {k: t[o:o + int(np.prod(s))].view(s).clone() for k, (o, s) in self.slot_table.items()}
+
+    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad():
+            for k, (o, s) in self.slot_table.items():
+                self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
+
+    # -- batch ----------------------------------------------------------------------------------
+    def _make_cfg(self, B: int, natoms: np.ndarray) -> _lib.CovCfg:
+        cfg = _lib.CovCfg()
+        cfg.B, cfg.N, cfg.Z = B, self.observation_space.canvas_space.size, len(self.zs)
+        for i, z in enumerate(self.zs):
+            cfg.zs[i] = int(z)
+        cfg.W, cfg.G = self.network_width, self.num_gaussians
+        cfg.TA, cfg.TE = int(natoms.sum()), int((natoms.astype(np.int64)**2).sum())
+        cfg.has_beta = 0 if self.beta is None else 1
+        cfg.beta = 0.0 if self.beta is None else float(self.beta)
+        cfg.bag_scale = float(self.bag_scale)
+        cfg.min_distance, cfg.max_distance = float(self.min_distance), float(self.max_distance)
+        return cfg
+
+    def to_action_space(self, action: np.ndarray, observation: ObservationType):
+        assert action.shape == (6, )
+        focus, element_index = int(round(float(action[0]))), int(round(float(action[1])))
+        atoms, _ = self.observation_space.parse_positions(observation)
+        if len(atoms):
+            position = tuple(np.asarray(atoms[focus][1]) + action[2] * action[3:6])
+        else:
+            position = (0.0, 0.0, 0.0)
+        return element_index, position
+
+    def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
+        if self.theta.device.type != 'cuda':
+            raise RuntimeError('CovariantAC runs on the HIP device only (no CPU fallback)')
+        if actions is None:
+            raise NotImplementedError('sampling path (rollout) is not on the device yet; see DESIGN.md')
+        N = self.observation_space.canvas_space.size
+        pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
+        B = len(observations)
+        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
+        assert acts.shape == (B, 6)
+        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
+        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
+            raise RuntimeError('index out of range in one-hot selection')  # to_one_hot's scatter_ error
+        cfg = self._make_cfg(B, natoms)
+        dev = self.theta.device
+        d_pos = torch.from_numpy(pos).to(dev, non_blocking=True)
+        d_chg = torch.from_numpy(charges).to(dev, non_blocking=True)
+        d_bag = torch.from_numpy(bags).to(dev, non_blocking=True)
+        d_act = torch.from_numpy(acts).to(dev, non_blocking=True)
+        out = _CovStep.apply(self.theta, self, cfg, d_pos, d_chg, d_bag, d_act)
+        return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
+
+    def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
+        """float32 view of a named intermediate of the last forward (tests only)."""
+        off, cnt = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().mg_cov_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))
+        return self._last_ws.view(torch.float32)[off.value:off.value + cnt.value]

@@ -1,0 +1,99 @@
+// common.h -- shared device helpers for the gfx950 kernels (hand-written HIP, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MAXL 4
+#define NLM 25   // sum_l (2l+1), l <= 4
+#define CH 10    // num_channels_hidden
+#define CE 4     // num_channels_per_element
+#define NLEV 3   // num_cg_levels
+#define NRADF 32 // radial features per level
+#define NLEB 1730
+#define LEB_STRIDE 51
+
+struct cf {  // complex float
+  float r, i;
+};
+__host__ __device__ __forceinline__ cf cmul(cf a, cf b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+__host__ __device__ __forceinline__ cf cmulc(cf a, cf b) {  // a * conj(b)
+  return {a.r * b.r + a.i * b.i, a.i * b.r - a.r * b.i};
+}
+__host__ __device__ __forceinline__ void cmac(cf& acc, cf a, cf b) {
+  acc.r = fmaf(a.r, b.r, acc.r);
+  acc.r = fmaf(-a.i, b.i, acc.r);
+  acc.i = fmaf(a.r, b.i, acc.i);
+  acc.i = fmaf(a.i, b.r, acc.i);
+}
+__host__ __device__ __forceinline__ void cmacc(cf& acc, cf a, cf b) {  // acc += a * conj(b)
+  acc.r = fmaf(a.r, b.r, acc.r);
+  acc.r = fmaf(a.i, b.i, acc.r);
+  acc.i = fmaf(a.i, b.r, acc.i);
+  acc.i = fmaf(-a.r, b.i, acc.i);
+}
+
+__host__ __device__ __forceinline__ int lm_l(int idx) { return idx < 1 ? 0 : idx < 4 ? 1 : idx < 9 ? 2 : idx < 16 ? 3 : 4; }
+__host__ __device__ __forceinline__ int lm_m(int idx, int l) { return idx - l * l - l; }
+
+// Standard (Condon-Shortley, 'qm') complex spherical harmonics Y_l^m, l <= 4, of a UNIT
+// vector; index l*l + m + l.  A zero vector gives Y_00 only (cormorant: x/|x| -> 0).
+__host__ __device__ inline void ylm25(float x, float y, float z, bool nonzero, float* yr, float* yi) {
+  yr[0] = 0.28209479177387814f;
+  yi[0] = 0.f;
+  if (!nonzero) {
+    for (int k = 1; k < NLM; ++k) { yr[k] = 0.f; yi[k] = 0.f; }
+    return;
+  }
+  const float c1r = x, c1i = y;
+  const float c2r = x * x - y * y, c2i = 2.f * x * y;
+  const float c3r = c2r * x - c2i * y, c3i = c2r * y + c2i * x;
+  const float c4r = c2r * c2r - c2i * c2i, c4i = 2.f * c2r * c2i;
+  const float z2 = z * z;
+  float q;
+  // l = 1
+  yr[2] = 0.4886025119029199f * z; yi[2] = 0.f;
+  q = -0.3454941494713355f;
+  yr[3] = q * c1r; yi[3] = q * c1i; yr[1] = -q * c1r; yi[1] = q * c1i;
+  // l = 2
+  yr[6] = 0.6307831305050401f * 0.5f * (3.f * z2 - 1.f); yi[6] = 0.f;
+  q = 0.2575161346821264f * (-3.f * z);
+  yr[7] = q * c1r; yi[7] = q * c1i; yr[5] = -q * c1r; yi[5] = q * c1i;
+  q = 0.1287580673410632f * 3.f;
+  yr[8] = q * c2r; yi[8] = q * c2i; yr[4] = q * c2r; yi[4] = -q * c2i;
+  // l = 3
+  yr[12] = 0.7463526651802308f * 0.5f * (5.f * z2 - 3.f) * z; yi[12] = 0.f;
+  q = 0.21545345607610045f * (-0.5f) * (15.f * z2 - 3.f);
+  yr[13] = q * c1r; yi[13] = q * c1i; yr[11] = -q * c1r; yi[11] = q * c1i;
+  q = 0.06813236509555216f * 15.f * z;
+  yr[14] = q * c2r; yi[14] = q * c2i; yr[10] = q * c2r; yi[10] = -q * c2i;
+  q = 0.02781492157551894f * (-15.f);
+  yr[15] = q * c3r; yi[15] = q * c3i; yr[9] = -q * c3r; yi[9] = q * c3i;
+  // l = 4
+  yr[20] = 0.8462843753216345f * 0.125f * ((35.f * z2 - 30.f) * z2 + 3.f); yi[20] = 0.f;
+  q = 0.18923493915151202f * (-2.5f) * (7.f * z2 - 3.f) * z;
+  yr[21] = q * c1r; yi[21] = q * c1i; yr[19] = -q * c1r; yi[19] = q * c1i;
+  q = 0.044603102903819275f * 7.5f * (7.f * z2 - 1.f);
+  yr[22] = q * c2r; yi[22] = q * c2i; yr[18] = q * c2r; yi[18] = -q * c2i;
+  q = 0.011920680675222404f * (-105.f) * z;
+  yr[23] = q * c3r; yi[23] = q * c3i; yr[17] = -q * c3r; yi[17] = q * c3i;
+  q = 0.004214597070904597f * 105.f;
+  yr[24] = q * c4r; yi[24] = q * c4i; yr[16] = q * c4r; yi[16] = -q * c4i;
+}
+
+// sqrt(4 pi / (2l+1)): 'unit' normalisation used by the relative harmonics.
+__host__ __device__ __forceinline__ float unit_norm(int l) {
+  const float t[5] = {3.5449077018110318f, 2.0466534158929770f, 1.5853309190424043f, 1.3398342629807677f,
+                      1.1816359006036772f};
+  return t[l];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,274 @@
+// molgym_hip.hip -- C-ABI entry points (include/molgym_hip.h) for the gfx950 PPO hot path.
+// One translation unit: kernels live in the .inc files next to this one.
+#include "state.inc"
+#include "backward.inc"
+#include "ppo.inc"
+
+static bool g_tables_ready = false;
+static int ensure_tables() {
+  if (g_tables_ready) return MG_OK;
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_nblk), h_cg_nblk, sizeof(h_cg_nblk)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_row_base), h_cg_row_base, sizeof(h_cg_row_base)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_row_start), h_cg_row_start, sizeof(h_cg_row_start)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_t_i1), h_cg_t_i1, sizeof(h_cg_t_i1)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_t_i2), h_cg_t_i2, sizeof(h_cg_t_i2)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_t_c), h_cg_t_c, sizeof(h_cg_t_c)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_start), h_cgT_start, sizeof(h_cgT_start)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_l), h_cgT_l, sizeof(h_cgT_l)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_blk), h_cgT_blk, sizeof(h_cgT_blk)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_c), h_cgT_c, sizeof(h_cgT_c)));
+  HIP_CHECK(hipDeviceSynchronize());
+  g_tables_ready = true;
+  return MG_OK;
+}
+
+extern "C" const char* mg_last_error(void) { return g_err; }
+extern "C" int mg_abi_version(void) { return 1; }
+
+extern "C" int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params) {
+  PLayout P;
+  int rc = build_layout(cfg, &P);
+  if (rc) return rc;
+  *num_params = P.total;
+  return MG_OK;
+}
+
+extern "C" int mg_cov_param_offsets(const mg_cov_cfg* cfg, int64_t* out, int32_t* n_slots) {
+  PLayout P;
+  int rc = build_layout(cfg, &P);
+  if (rc) return rc;
+  if (out) {
+    for (size_t i = 0; i < P.slots.size(); ++i) out[i] = P.slots[i];
+    out[P.slots.size()] = P.total;
+  }
+  *n_slots = (int32_t)P.slots.size();
+  return MG_OK;
+}
+
+extern "C" int mg_cov_workspace_bytes(const mg_cov_cfg* cfg, size_t* bytes) {
+  PLayout P;
+  int rc = build_layout(cfg, &P);
+  if (rc) return rc;
+  WS w;
+  rc = ws_build(cfg, P, nullptr, &w, nullptr);
+  if (rc) return rc;
+  *bytes = w.bytes;
+  return MG_OK;
+}
+
+extern "C" int mg_cov_workspace_lookup(const mg_cov_cfg* cfg, const char* name, int64_t* off, int64_t* count) {
+  PLayout P;
+  int rc = build_layout(cfg, &P);
+  if (rc) return rc;
+  WS w;
+  Arena ar;
+  rc = ws_build(cfg, P, nullptr, &w, &ar);
+  if (rc) return rc;
+  for (size_t i = 0; i < ar.names.size(); ++i)
+    if (ar.names[i] == name) {
+      *off = (int64_t)(ar.offs[i] / sizeof(float));
+      *count = (int64_t)ar.counts[i];
+      return MG_OK;
+    }
+  MG_FAIL(MG_EINVAL, "no workspace entry named '%s'", name);
+}
+
+static int check_common(const mg_cov_cfg* c, const PLayout& P, const WS& w, size_t ws_bytes) {
+  (void)P;
+  if (c->B < 1) MG_FAIL(MG_EINVAL, "B must be >= 1");
+  if (c->TA < 0 || c->TA > c->B * c->N) MG_FAIL(MG_EINVAL, "TA=%d inconsistent with B*N", c->TA);
+  if (c->TE < c->TA || (long)c->TE > (long)c->TA * c->N) MG_FAIL(MG_EINVAL, "TE=%d inconsistent", c->TE);
+  if (ws_bytes < w.bytes) MG_FAIL(MG_ENOMEM, "workspace %zu bytes < required %zu", ws_bytes, w.bytes);
+  if (!(c->min_distance < c->max_distance)) MG_FAIL(MG_EINVAL, "min_distance must be < max_distance");
+  return MG_OK;
+}
+
+static int prep_weights(hipStream_t s, const float* theta, WS& w) {
+  std::vector<Lin*> all;
+  for (int k = 0; k < 3; ++k)
+    for (int l = 0; l < 5; ++l) { all.push_back(&w.rad[k][l]); all.push_back(&w.edge[k][l]); all.push_back(&w.atom[k][l]); }
+  all.push_back(&w.lin_in);
+  for (int l = 0; l < 5; ++l) all.push_back(&w.mix[l]);
+  for (int m = 0; m < NMLP; ++m) { all.push_back(&w.mlp[m][0]); all.push_back(&w.mlp[m][1]); }
+  for (size_t i0 = 0; i0 < all.size(); i0 += WPREP_MAX) {
+    WPrepArgs a;
+    memset(&a, 0, sizeof(a));
+    const int n = (int)std::min((size_t)WPREP_MAX, all.size() - i0);
+    for (int i = 0; i < n; ++i) {
+      Lin* L = all[i0 + i];
+      a.w[i] = {theta + L->w_off, L->mf, L->mb, L->O, L->Q, L->ldf, L->ldb, L->cplx};
+    }
+    hipLaunchKernelGGL(k_prep_weights, dim3(8, n), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+  }
+  return MG_OK;
+}
+
+extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
+                              const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
+                              float* out, void* stream) {
+  PLayout P;
+  int rc = build_layout(c, &P);
+  if (rc) return rc;
+  WS w;
+  rc = ws_build(c, P, ws, &w, nullptr);
+  if (rc) return rc;
+  rc = check_common(c, P, w, ws_bytes);
+  if (rc) return rc;
+  rc = ensure_tables();
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int B = c->B, N = c->N, Z = c->Z, TA = c->TA, TE = c->TE, W = c->W;
+#define RC(x) do { rc = (x); if (rc) return rc; } while (0)
+  RC(prep_weights(s, theta, w));
+  HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
+  hipLaunchKernelGGL(k_prep_counts, dim3(1), dim3(256), 0, s, charges, B, N, TA, TE, w.L);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_fill_lists, dim3(B), dim3(64), 0, s, B, w.L);
+  LAUNCH_CHECK();
+  int maxz = 0;
+  ZsArr zs;
+  for (int i = 0; i < 8; ++i) { zs.z[i] = i < Z ? c->zs[i] : -1; if (i < Z && c->zs[i] > maxz) maxz = c->zs[i]; }
+  const float soft_rad = fmaxf(1e-3f, fminf(c->max_distance, 2.1f)), soft_width = 0.2f;
+  if (TE > 0) {
+    GeomOut go = {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}};
+    hipLaunchKernelGGL(k_geom, dim3((TE + 127) / 128), dim3(128), 0, s, TE, N, pos, w.L, theta, (int)P.rad_scales[0],
+                       (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]), soft_rad, soft_width, go);
+    LAUNCH_CHECK();
+  }
+  if (TA > 0) {
+    hipLaunchKernelGGL(k_atom_scalars, dim3((TA * 4 * Z + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
+                       c->bag_scale, charges, bags, w.L, w.scal);
+    LAUNCH_CHECK();
+    GemmG g = fwd_group(w.lin_in, theta, w.scal, 4 * Z, w.A0, 2 * CH, TA, 0, nullptr);
+    RC(launch_gemm(s, &g, 1));
+  }
+  for (int k = 0; k < 3 && TA > 0; ++k) {
+    // --- edge level k (cormorant EdgeLevel: DotMatrix, cat-mix, soft mask) ---
+    if (k == 0) {
+      hipLaunchKernelGGL(k_dot0, dim3((TE * CH + 255) / 256), dim3(256), 0, s, TE, w.L, w.A0, w.cat_e[0][0],
+                         w.ld_e[0][0], w.dcol[0]);
+    } else {
+      APtrs A;
+      for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
+      A.C = CH;
+      DotDst d;
+      for (int l = 0; l < 5; ++l) { d.p[l] = w.cat_e[k][l]; d.ld[l] = w.ld_e[k][l]; }
+      d.col = w.dcol[k];
+      d.nparts = 5;
+      hipLaunchKernelGGL(k_dot, dim3((TE * 50 + 255) / 256), dim3(256), 0, s, TE, w.L, A, d);
+    }
+    LAUNCH_CHECK();
+    GemmG gr[5], ge[5];
+    for (int l = 0; l < 5; ++l) {
+      gr[l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE, 0, nullptr);
+      float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+      const int ldE = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+      ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
+    }
+    RC(launch_gemm(s, gr, 5));
+    if (k == 0) {  // l = 0 has a different reduction width (and tile alignment) than l >= 1
+      RC(launch_gemm(s, ge, 1));
+      RC(launch_gemm(s, ge + 1, 4));
+    } else {
+      RC(launch_gemm(s, ge, 5));
+    }
+    // --- atom level k (CG aggregate, CG power, cat-mix) ---
+    EPtrs E;
+    for (int l = 0; l < 5; ++l) {
+      E.p[l] = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+      E.ld[l] = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+    }
+    CatDst cd;
+    for (int l = 0; l < 5; ++l) { cd.p[l] = w.cat_a[k][l]; cd.ld[l] = w.ld_a[k][l]; }
+    if (k == 0) {
+      hipLaunchKernelGGL(k_catbuild0, dim3(TA), dim3(256), 0, s, w.L, w.A0, E, w.Y, cd);
+    } else {
+      APtrs A;
+      for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
+      A.C = CH;
+      hipLaunchKernelGGL(k_catbuild, dim3(TA), dim3(256), CB_SMEM, s, w.L, A, E, w.Y, cd);
+    }
+    LAUNCH_CHECK();
+    GemmG ga[5];
+    for (int l = 0; l < 5; ++l)
+      ga[l] = fwd_group(w.atom[k][l], theta, w.cat_a[k][l], w.ld_a[k][l], w.A[k + 1][l], 2 * P.atom_cout[k],
+                        TA * (2 * l + 1), 0, nullptr);
+    RC(launch_gemm(s, ga, 5));
+  }
+  // --- heads ---
+  const int Co = P.Co, nlat = P.nlat;
+  APtrs A3;
+  for (int l = 0; l < 5; ++l) A3.p[l] = w.A[3][l];
+  A3.C = Co;
+  if (TA > 0) {
+    hipLaunchKernelGGL(k_scalars, dim3((TA * Co + 255) / 256), dim3(256), 0, s, TA, Co, A3, w.inv);
+    LAUNCH_CHECK();
+    GemmG g2[2] = {fwd_group(w.mlp[MLP_FOCUS][0], theta, w.inv, nlat, w.hF, W, TA, 1, nullptr),
+                   fwd_group(w.mlp[MLP_TRANS][0], theta, w.inv, nlat, w.hT, W, TA, 1, nullptr)};
+    RC(launch_gemm(s, g2, 2));
+    GemmG gf = fwd_group(w.mlp[MLP_FOCUS][1], theta, w.hF, W, w.logitF, 1, TA, 0, nullptr);
+    RC(launch_gemm(s, &gf, 1));
+    GemmG gt = fwd_group(w.mlp[MLP_TRANS][1], theta, w.hT, W, w.trans, W, TA, 0, nullptr);
+    RC(launch_gemm(s, &gt, 1));
+  }
+  float* parts = w.parts;
+  hipLaunchKernelGGL(k_focus_head, dim3((B + 63) / 64), dim3(64), 0, s, B, w.L, w.logitF, actions, parts, parts + 4 * B,
+                     w.fidx);
+  LAUNCH_CHECK();
+  EcovDst ec;
+  for (int l = 0; l < 5; ++l) ec.p[l] = w.ecov[l];
+  hipLaunchKernelGGL(k_gather_focus, dim3(B), dim3(256), 0, s, B, Co, nlat, w.fidx, actions, w.inv, A3, w.finv, ec);
+  LAUNCH_CHECK();
+  {
+    GemmG g = fwd_group(w.mlp[MLP_ELEMENT][0], theta, w.finv, nlat, w.hE, W, B, 1, nullptr);
+    RC(launch_gemm(s, &g, 1));
+    g = fwd_group(w.mlp[MLP_ELEMENT][1], theta, w.hE, W, w.logitE, Z, B, 0, nullptr);
+    RC(launch_gemm(s, &g, 1));
+  }
+  hipLaunchKernelGGL(k_element_head, dim3((B + 63) / 64), dim3(64), 0, s, B, Z, w.logitE, bags, actions, parts + B,
+                     parts + 5 * B);
+  LAUNCH_CHECK();
+  {
+    APtrs Ae;
+    for (int l = 0; l < 5; ++l) Ae.p[l] = w.ecov[l];
+    Ae.C = CE;
+    hipLaunchKernelGGL(k_scalars, dim3((B * CE + 255) / 256), dim3(256), 0, s, B, CE, Ae, w.einv);
+    LAUNCH_CHECK();
+    GemmG g = fwd_group(w.mlp[MLP_D][0], theta, w.einv, P.nlatE, w.hD, W, B, 1, nullptr);
+    RC(launch_gemm(s, &g, 1));
+    g = fwd_group(w.mlp[MLP_D][1], theta, w.hD, W, w.dout, 2 * c->G, B, 0, nullptr);
+    RC(launch_gemm(s, &g, 1));
+    const float half_w = (c->max_distance - c->min_distance) / 2, center = (c->max_distance + c->min_distance) / 2;
+    hipLaunchKernelGGL(k_gmm, dim3((B + 63) / 64), dim3(64), 0, s, B, c->G, w.dout, theta + P.logstd, actions, half_w,
+                       center, parts + 2 * B);
+    LAUNCH_CHECK();
+  }
+  {
+    CatDst cm;
+    for (int l = 0; l < 5; ++l) { cm.p[l] = w.cat_m[l]; cm.ld[l] = w.ld_m[l]; }
+    hipLaunchKernelGGL(k_mixer_cat, dim3((B * CE * NLM + 127) / 128), dim3(128), 0, s, B, actions, ec, cm);
+    LAUNCH_CHECK();
+    GemmG gm[5];
+    for (int l = 0; l < 5; ++l)
+      gm[l] = fwd_group(w.mix[l], theta, w.cat_m[l], w.ld_m[l], w.cond[l], 2 * CE, B * (2 * l + 1), 0, nullptr);
+    RC(launch_gemm(s, gm, 5));
+    CondPtrs cp;
+    for (int l = 0; l < 5; ++l) cp.p[l] = w.cond[l];
+    hipLaunchKernelGGL(k_so3, dim3(B), dim3(256), 0, s, B, w.L, cp, actions, leb, c->has_beta, c->beta, parts + 3 * B,
+                       w.logz);
+    LAUNCH_CHECK();
+  }
+  {
+    hipLaunchKernelGGL(k_value_sum, dim3((B * W + 255) / 256), dim3(256), 0, s, B, W, w.L, w.trans, w.vfeat);
+    LAUNCH_CHECK();
+    GemmG g = fwd_group(w.mlp[MLP_V][0], theta, w.vfeat, W, w.hV, W, B, 1, nullptr);
+    RC(launch_gemm(s, &g, 1));
+    g = fwd_group(w.mlp[MLP_V][1], theta, w.hV, W, out + 2 * B, 1, B, 0, nullptr);
+    RC(launch_gemm(s, &g, 1));
+  }
+  hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, B, parts, out);
+  LAUNCH_CHECK();
+#undef RC
+  return MG_OK;
+}

@@ -1,0 +1,71 @@
+"""Flat parameter vector of the covariant actor-critic.
+
+theta is ONE float32 vector; a slot is a named tensor inside it.  Slot names are
+the ``state_dict`` keys the reference module would have
+(/root/reference/molgym/agents/covariant/agent.py:58-143 and
+covariant/modules.py:52-95,155-178 give the attribute names), so
+``export_state_dict`` / ``import_state_dict`` map 1:1 to a CovariantAC checkpoint.
+The C side (molgym_amd/csrc/state.inc, build_layout) computes the same offsets;
+tests cross-check them through mg_cov_param_offsets.
+"""
+from collections import OrderedDict
+from typing import Tuple
+
+MAXL, NLEV, CH, CE, NRADF = 4, 3, 10, 4, 32
+NBLK = (5, 12, 16, 17, 15)
+
+
+def edge_cin(k: int, l: int) -> int:
+    return (2 * CH if l == 0 else CH) if k == 0 else 7 * CH
+
+
+def atom_tau(k: int, l: int) -> int:
+    return (3 * CH if l == 0 else CH) if k == 0 else CH * (2 * NBLK[l] + 1)
+
+
+def mix_tau(l: int) -> int:
+    return CE * (NBLK[l] + 2)
+
+
+def slots(num_zs: int, width: int, num_gaussians: int) -> 'OrderedDict[str, Tuple[int, ...]]':
+    co = num_zs * CE
+    nlat, nlat_e = (MAXL + 2) * co * 2, (MAXL + 2) * CE * 2
+    s: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
+    for k in range(NLEV):
+        base = f'cg_model.rad_funcs.rad_funcs.{k}'
+        s[f'{base}.scales'] = (1, 1, 1, 8)
+        s[f'{base}.phases'] = (1, 1, 1, 8)
+        for l in range(MAXL + 1):
+            s[f'{base}.linear.{l}.weight'] = (2 * CH, NRADF)
+            s[f'{base}.linear.{l}.bias'] = (2 * CH, )
+    s['cg_model.input_func_atom.lin.weight'] = (2 * CH, 4 * num_zs)
+    s['cg_model.input_func_atom.lin.bias'] = (2 * CH, )
+    for k in range(NLEV):
+        for l in range(MAXL + 1):
+            s[f'cg_model.cormorant_cg.edge_levels.{k}.cat_mix.weights.{l}'] = (CH, edge_cin(k, l), 2)
+    for k in range(NLEV):
+        cout = co if k == NLEV - 1 else CH
+        for l in range(MAXL + 1):
+            s[f'cg_model.cormorant_cg.atom_levels.{k}.cat_mix.weights.{l}'] = (cout, atom_tau(k, l), 2)
+    for l in range(MAXL + 1):
+        s[f'cg_mix.cat_mix.weights.{l}'] = (CE, mix_tau(l), 2)
+    for name, n_in, n_out in (('phi_focus', nlat, 1), ('phi_element', nlat, num_zs),
+                              ('phi_d', nlat_e, 2 * num_gaussians), ('phi_trans', nlat, width), ('phi_v', width, 1)):
+        s[f'{name}.layers.0.weight'] = (width, n_in)
+        s[f'{name}.layers.0.bias'] = (width, )
+        s[f'{name}.layers.1.weight'] = (n_out, width)
+        s[f'{name}.layers.1.bias'] = (n_out, )
+    s['distance_log_stds'] = (num_gaussians, )
+    return s
+
+
+def offsets(num_zs: int, width: int, num_gaussians: int):
+    """name -> (offset, shape); also returns the total length."""
+    out, off = OrderedDict(), 0
+    for name, shape in slots(num_zs, width, num_gaussians).items():
+        n = 1
+        for d in shape:
+            n *= d
+        out[name] = (off, shape)
+        off += n
+    return out, off

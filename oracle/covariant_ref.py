@@ -171,7 +171,9 @@ def parse_observations(observations, zs, canvas_size, dtype=torch.float32):
                 k += 1
         counts[b] = k
     data = {
-        'positions': torch.tensor(pos, dtype=dtype),
+        # the reference builds float32 tensors (covariant/tools.py:13); a float64 oracle sees the same
+        # float32-quantised inputs, so it is the exact-arithmetic value of the float32 computation
+        'positions': torch.tensor(pos, dtype=torch.float32).to(dtype),
         'charges': torch.tensor(charges, dtype=torch.int32),
         'num_atoms': torch.tensor(counts, dtype=torch.int32),
     }
@@ -224,7 +226,7 @@ class CovariantACRef(nn.Module):
         if actions is None:
             raise NotImplementedError('oracle covers the action-evaluation path only')
         data = parse_observations(observations, self.zs, self.canvas_size, dtype)
-        actions = torch.as_tensor(actions, dtype=dtype)
+        actions = torch.as_tensor(actions, dtype=torch.float32).to(dtype)  # agent.py:214 casts to float32
         B, N, ce = len(observations), self.canvas_size, self.num_channels_per_element
         covariats = self.cg_model(data)
         invariats = atomic_scalars(covariats, self.max_sh)

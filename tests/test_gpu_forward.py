@@ -1,0 +1,123 @@
+"""Forward parity of the HIP CovariantAC.step against the CPU oracle (float64), stage by stage."""
+import numpy as np
+import pytest
+import torch
+
+from molgym_amd.synthetic import make_batch
+from tests.helpers import compact_edges, compact_vec, make_pair, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg_name='cfg2', B=24, seed=0, beta='cfg'):
+    ac, ref, cfg = make_pair(cfg_name, seed=seed, beta=beta)
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=seed + 3)
+    with torch.no_grad():
+        out = ac.step(data['obs'], data['act'])
+        exp = ref.step(data['obs'], data['act'], dtype=torch.float64, return_internals=True)
+    torch.cuda.synchronize()
+    return ac, ref, cfg, data, out, exp
+
+
+def test_outputs_match_oracle(built_lib):
+    ac, ref, cfg, data, out, exp = _run()
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_outputs_match_oracle_so3_without_beta(built_lib):
+    ac, ref, cfg, data, out, exp = _run(beta=None, seed=2)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_outputs_match_oracle_five_elements(built_lib):
+    ac, ref, cfg, data, out, exp = _run('cfg3', B=16, seed=1)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_encoder_stages(built_lib):
+    """Every saved intermediate of the encoder against the oracle's, to localise a deviation."""
+    ac, ref, cfg, data, out, exp = _run(B=12, seed=5)
+    from oracle.covariant_ref import parse_observations
+    d = parse_observations(data['obs'], cfg['zs'], cfg['canvas_size'], torch.float64)
+    with torch.no_grad():
+        atoms_all, edges_all, extra = ref.cg_model(d, return_all=True)
+    am, em = d['atom_mask'], d['edge_mask']
+    natoms = d['num_atoms'].numpy()
+    ccfg = ac._make_cfg(len(data['obs']), natoms)
+    report = {}
+
+    def chk(name, want, floor=1e-2):
+        got = ac.workspace_view(name, ccfg)[:want.numel()].view(want.shape).double().cpu()
+        report[name] = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+
+    chk('r', extra['norms'][em])
+    TE = int(em.sum())
+    y_want = torch.cat([p[em].reshape(TE, -1) for p in extra['sph']], dim=1)
+    chk('Y', y_want)
+    chk('A0', extra['atom_in'][0][am].reshape(int(am.sum()), -1))
+    for k in range(3):
+        a_parts = compact_vec(atoms_all[k], am)
+        for l in range(5):
+            chk(f'A{k + 1}_{l}', a_parts[l])
+    e_last = compact_edges(edges_all[2], em)
+    for l in range(5):
+        chk(f'Elast_{l}', e_last[l])
+    chk('inv', exp['invariats'][am])
+    bad = {k: v for k, v in report.items() if not v < 1e-5}
+    assert not bad, f'stages off: {bad}; all: {report}'
+
+
+def test_head_parts(built_lib):
+    ac, ref, cfg, data, out, exp = _run(B=20, seed=7)
+    natoms = exp['data']['num_atoms'].numpy()
+    ccfg = ac._make_cfg(len(data['obs']), natoms)
+    B = len(data['obs'])
+    parts = ac.workspace_view('parts', ccfg).view(6, B)
+    names = ['focus', 'element', 'distance', 'so3']
+    for i, n in enumerate(names):
+        assert rel_err(parts[i], exp['logps'][i]) < 1e-5, n
+    assert rel_err(parts[4], exp['ent_parts'][0], floor=1e-3) < 1e-4
+    assert rel_err(parts[5], exp['ent_parts'][1], floor=1e-3) < 1e-4
+    assert rel_err(ac.workspace_view('logz', ccfg), exp['log_z']) < 1e-5
+
+
+def test_empty_and_full_canvases(built_lib):
+    """n = 0 (empty canvas: focus on slot 0, zero covariants) and n = N in the same batch."""
+    ac, ref, cfg = make_pair('cfg2', seed=11)
+    data = make_batch(6, cfg['canvas_size'], cfg['zs'], seed=4)  # make_batch forces counts[0]=0, counts[1]=N
+    with torch.no_grad():
+        out = ac.step(data['obs'], data['act'])
+        exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_all_empty_batch(built_lib):
+    ac, ref, cfg = make_pair('cfg2', seed=12)
+    data = make_batch(3, cfg['canvas_size'], cfg['zs'], seed=5)
+    N = cfg['canvas_size']
+    empty = tuple([(0, (0.0, 0.0, 0.0))] * N)
+    obs = [(empty, o[1]) for o in data['obs']]
+    act = data['act'].copy()
+    act[:, 0] = 0
+    with torch.no_grad():
+        out = ac.step(obs, act)
+        exp = ref.step(obs, act, dtype=torch.float64)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_bad_indices_raise(built_lib):
+    ac, ref, cfg = make_pair('cfg2', seed=13)
+    data = make_batch(4, cfg['canvas_size'], cfg['zs'], seed=6)
+    act = data['act'].copy()
+    act[0, 0] = cfg['canvas_size']  # focus out of range -> to_one_hot raises in the reference
+    with pytest.raises(RuntimeError):
+        ac.step(data['obs'], act)
+    act = data['act'].copy()
+    act[1, 1] = len(cfg['zs'])
+    with pytest.raises(RuntimeError):
+        ac.step(data['obs'], act)
