@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""PPO mini-batch forward+backward throughput of the covariant actor-critic on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic mini-batch (molgym/ppo.py:124-131):
+``step(obs, actions)`` -> float64 PPO loss -> backward into ``.grad`` (optimizer step excluded), with
+the parsed mini-batch already resident in HBM.  N > 1: one process per GPU (torchrun), every rank owns
+its own mini-batch of the same size (weak scaling), and the flat gradient is all-reduced over RCCL
+inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3  # MI355X f32 vector == f32-input MFMA dense peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--config', default='cfg2', help='synthetic workload (molgym_amd/synthetic.py)')
+    p.add_argument('--batch', type=int, default=None, help='override the mini-batch size per GPU')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
+    return p.parse_args()
+
+
+def _cpu_baseline_worker(cfg_name, B, seed, budget_s, threads, sd_path):
+    """Runs in a child process (bounded by a timeout in the parent)."""
+    import torch
+    from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch
+    from oracle.covariant_ref import CovariantACRef
+    from oracle.ppo_ref import compute_loss_ref
+    cfg = CONFIGS[cfg_name]
+    torch.set_num_threads(threads)
+    ref = CovariantACRef(zs=cfg['zs'], canvas_size=cfg['canvas_size'], bag_scale=cfg['bag_scale'], beta=cfg['beta'],
+                         **MODEL_DEFAULTS)
+    ref.load_state_dict(torch.load(sd_path))
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=seed)
+
+    def one():
+        for p in ref.parameters():
+            p.grad = None
+        loss, _ = compute_loss_ref(ref, data, 0.2, 0.5, 0.01)
+        loss.backward()
+
+    one()  # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    print(json.dumps({'dt': (time.perf_counter() - t0) / n, 'n': n}))
+
+
+def cpu_baseline(cfg_name, B, seed, state_dict, budget_s):
+    """Reference-equivalent CPU restatement (oracle/) timed on the host cores: checker/baseline only.
+    The GPU box has hundreds of cores and this path is thousands of tiny ATen ops, where an OpenMP team
+    of os.cpu_count() threads is pathologically slow -- a few team sizes are tried, the best is reported."""
+    import subprocess
+    import tempfile
+    import torch
+    cores = os.cpu_count() or 1
+    with tempfile.TemporaryDirectory() as tmp:
+        sd_path = os.path.join(tmp, 'sd.pt')
+        torch.save(state_dict, sd_path)
+        best = None
+        cands = sorted({min(cores, t) for t in (8, 32)})
+        for threads in cands:
+            code = ('import sys; sys.path.insert(0, %r); import bench; '
+                    'bench._cpu_baseline_worker(%r, %d, %d, %f, %d, %r)' %
+                    (ROOT, cfg_name, B, seed, budget_s / len(cands), threads, sd_path))
+            try:
+                res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                                     timeout=4 * budget_s + 120)
+                rec = json.loads(res.stdout.strip().splitlines()[-1])
+            except Exception:  # timed out / failed: skip this team size
+                continue
+            if best is None or rec['dt'] < best[0]:
+                best = (rec['dt'], rec['n'], threads)
+    if best is None:
+        return None
+    dt, n, threads = best
+    return {'value': B / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} fwd+bwd passes over the same {B}-sample mini-batch, float32, torch {torch.__version__}, '
+                      f'{threads} threads (best of {cands}; host has {cores} cores), oracle/ restatement at the '
+                      f'reference op granularity'}
+
+
+def main():
+    args = parse_args()
+    wd = float(os.environ.get('BENCH_WATCHDOG', '0'))
+    if wd > 0:  # dump all Python stacks and exit if the run wedges
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+
+    from molgym_amd import _lib
+    from molgym_amd.agents.covariant import CovariantAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch
+    from tools.flops import forward_flops, step_flops
+
+    cfg = dict(CONFIGS[args.config])
+    B = args.batch or cfg['batch']
+    torch.manual_seed(0)
+    ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']),
+                     bag_scale=cfg['bag_scale'], beta=cfg['beta'], device=dev, **MODEL_DEFAULTS)
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=rank)
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    inv_world = 1.0 / world
+
+    def step():
+        ac.theta.grad.zero_()
+        stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world)
+        if world > 1:
+            dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
+        return stats
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if not torch.isfinite(stats).all():
+        raise SystemExit('non-finite loss statistics')
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        natoms = [sum(1 for it in o[0] if cfg['zs'][it[0]] != 0) for o in data['obs']]
+        f_dense = 3 * forward_flops(cfg['canvas_size'], len(cfg['zs']))  # SURVEY 8(d) per-sample figure
+        f_ragged = step_flops(natoms, len(cfg['zs'])) / B
+        # dominant kernel, timed live with HIP events on the launch stream
+        from molgym_amd.profile import dominant_kernel_roofline
+        roof = dominant_kernel_roofline(ac, batch, natoms, cfg)
+        line = {
+            'metric': 'PPO mini-batch fwd+bwd samples/sec (covariant, canvas_size=%d)' % cfg['canvas_size'],
+            'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.config}: covariant actor-critic, zs={cfg["zs"]}, canvas_size='
+                                   f'{cfg["canvas_size"]}, mini_batch={B} per GPU, beta={cfg["beta"]}, random-walk '
+                                   f'canvases with U{{0..N}} atoms, inputs resident in HBM',
+                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'step_tflops_dense_convention': f_dense * value / 1e12,
+                       'step_tflops_ragged': f_ragged * value / 1e12,
+                       'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world)},
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sd = {k: v.float().cpu() for k, v in ac.export_state_dict().items()}
+            line['cpu_baseline'] = cpu_baseline(args.config, B, rank, sd, args.cpu_seconds)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -52,6 +52,14 @@ def parse_observations_host(observations: List[ObservationType], zs: List[int], 
     return xyz.astype(np.float32), np.ascontiguousarray(charges), bags, natoms
 
 
+class DeviceBatch:
+    """One PPO mini-batch resident in HBM (layout of include/molgym_hip.h)."""
+
+    def __init__(self, cfg, pos, charges, bags, actions, logp=None, adv=None, ret=None):
+        self.cfg, self.pos, self.charges, self.bags, self.actions = cfg, pos, charges, bags, actions
+        self.logp, self.adv, self.ret = logp, adv, ret
+
+
 class _CovStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, theta, ac, cfg, pos, charges, bags, actions):
@@ -205,6 +213,65 @@ class CovariantAC(AbstractActorCritic):
         d_act = torch.from_numpy(acts).to(dev, non_blocking=True)
         out = _CovStep.apply(self.theta, self, cfg, d_pos, d_chg, d_bag, d_act)
         return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
+
+    # -- device-resident mini-batches (the PPO fast path: no autograd graph, no host sync) ---------
+    def prepare_batch(self, observations: List[ObservationType], actions: np.ndarray, logp=None, adv=None,
+                      ret=None) -> 'DeviceBatch':
+        """Parse on the host once and park everything a PPO mini-batch needs in HBM."""
+        N = self.observation_space.canvas_space.size
+        pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
+        B = len(observations)
+        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
+        assert acts.shape == (B, 6)
+        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
+        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
+            raise RuntimeError('index out of range in one-hot selection')
+        dev = self.theta.device
+        f64 = lambda x: None if x is None else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+        return DeviceBatch(self._make_cfg(B, natoms), torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
+                           torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(logp), f64(adv),
+                           f64(ret))
+
+    def _workspace(self, cfg: _lib.CovCfg) -> torch.Tensor:
+        nbytes = C.c_size_t()
+        _lib.check(_lib.lib().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        ws = getattr(self, '_ws_cache', None)
+        if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
+            ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
+            self._ws_cache = ws
+        return ws
+
+    def forward_batch(self, batch: 'DeviceBatch') -> torch.Tensor:
+        """(3, B) float32: logp, ent, v -- no autograd graph."""
+        ws = self._workspace(batch.cfg)
+        out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
+        _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+                                             _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
+                                             ws.numel(), _ptr(out), _stream()))
+        self._last_ws = ws
+        return out
+
+    def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
+                      loss_scale: float = 1.0) -> torch.Tensor:
+        """One compute_loss forward + backward (molgym/ppo.py:124-131) entirely on the device:
+        step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED into theta.grad.
+        Returns the 6 float64 loss statistics (device tensor, no sync)."""
+        lib = _lib.lib()
+        out = self.forward_batch(batch)
+        ws = self._last_ws
+        B = batch.cfg.B
+        stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
+        gout = torch.empty(3, B, dtype=torch.float32, device=self.theta.device)
+        _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
+                                   vf_coef, entropy_coef, _ptr(stats), _ptr(gout), _stream()))
+        if loss_scale != 1.0:
+            gout.mul_(loss_scale)
+        if self.theta.grad is None:
+            self.theta.grad = torch.zeros_like(self.theta)
+        _lib.check(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+                                       _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
+                                       _ptr(gout), _ptr(self.theta.grad), _stream()))
+        return stats
 
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""
