@@ -1,0 +1,100 @@
+"""Host-side logic that needs no GPU: observation parsing, parameter layout, the C ABI surface."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from molgym_amd import layout
+from molgym_amd.agents.covariant import parse_observations_host
+from molgym_amd.lebedev import lebedev_table
+from molgym_amd.synthetic import CONFIGS, make_batch
+from oracle.covariant_ref import parse_observations
+
+
+def test_parse_matches_oracle_and_compacts_null_items():
+    cfg = CONFIGS['cfg2']
+    data = make_batch(9, cfg['canvas_size'], cfg['zs'], seed=2)
+    obs = list(data['obs'])
+    # a null item in the middle of a canvas must be dropped and the rest compacted (spaces.py:55-61)
+    c, bag = obs[1]
+    c = list(c)
+    c[2] = (0, (0.0, 0.0, 0.0))
+    obs[1] = (tuple(c), bag)
+    pos, charges, bags, natoms = parse_observations_host(obs, cfg['zs'], cfg['canvas_size'])
+    ref = parse_observations(obs, cfg['zs'], cfg['canvas_size'])
+    np.testing.assert_array_equal(charges, ref['charges'].numpy())
+    np.testing.assert_allclose(pos, ref['positions'].numpy())
+    np.testing.assert_array_equal(natoms, ref['num_atoms'].numpy())
+    np.testing.assert_array_equal(bags, ref['bags'].numpy())
+    assert natoms[0] == 0 and natoms[1] == cfg['canvas_size'] - 1
+
+
+def test_parse_rejects_malformed_input():
+    cfg = CONFIGS['cfg2']
+    data = make_batch(2, cfg['canvas_size'], cfg['zs'], seed=0)
+    with pytest.raises(RuntimeError):
+        parse_observations_host([(data['obs'][0][0][:3], data['obs'][0][1])], cfg['zs'], cfg['canvas_size'])
+    with pytest.raises(RuntimeError):
+        bad = ((99, (0., 0., 0.)), ) * cfg['canvas_size']
+        parse_observations_host([(bad, data['obs'][0][1])], cfg['zs'], cfg['canvas_size'])
+
+
+def test_layout_matches_library_and_reference_counts(built_lib):
+    from molgym_amd import _lib
+    for zs, width, total in (([0, 9, 16], 128, 185006), ([0, 1, 6, 7, 8], 128, None), ([0, 1, 6, 8], 64, None)):
+        table, n = layout.offsets(len(zs), width, 3)
+        cfg = _lib.CovCfg()
+        cfg.B, cfg.N, cfg.Z, cfg.W, cfg.G, cfg.TA, cfg.TE = 2, 7, len(zs), width, 3, 3, 5
+        for i, z in enumerate(zs):
+            cfg.zs[i] = z
+        cfg.min_distance, cfg.max_distance, cfg.bag_scale = 0.8, 1.8, 5
+        cnt = C.c_int64()
+        _lib.check(built_lib.mg_cov_num_params(C.byref(cfg), C.byref(cnt)))
+        assert cnt.value == n and (total is None or n == total)
+        offs = (C.c_int64 * 256)()
+        ns = C.c_int32()
+        _lib.check(built_lib.mg_cov_param_offsets(C.byref(cfg), offs, C.byref(ns)))
+        assert ns.value == len(table)
+        assert [offs[i] for i in range(ns.value)] == [o for o, _ in table.values()]
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    import os
+    from molgym_amd import _lib
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include',
+                               'molgym_hip.h')).read()
+    declared = set(re.findall(r'\b(mg_[a-z0-9_]+)\s*\(', header)) - {'mg_cov_cfg'}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(built_lib, name)
+    assert built_lib.mg_abi_version() == 1
+
+
+def test_invalid_configuration_is_reported(built_lib):
+    from molgym_amd import _lib
+    cfg = _lib.CovCfg()
+    cfg.B, cfg.N, cfg.Z, cfg.W, cfg.G = 1, 7, 1, 128, 3
+    n = C.c_int64()
+    assert built_lib.mg_cov_num_params(C.byref(cfg), C.byref(n)) < 0
+    assert b'Z=' in built_lib.mg_last_error()
+
+
+def test_lebedev_table_integrates_harmonics_exactly():
+    tab = lebedev_table().astype(np.float64)
+    w = np.exp(tab[50])
+    assert abs(w.sum() - 1) < 1e-6
+    y = tab[0:50:2] + 1j * tab[1:50:2]  # (25, 1730)
+    gram = (y * w) @ y.conj().T * 4 * np.pi  # orthonormality of Y_lm under the quadrature
+    np.testing.assert_allclose(gram, np.eye(25), atol=2e-6)
+
+
+def test_product_path_never_imports_the_oracle():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, 'molgym_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f

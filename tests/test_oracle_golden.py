@@ -1,0 +1,145 @@
+"""Pin the oracle against vectors produced by the reference's own code (oracle/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import so3
+from oracle.covariant_ref import (GMMRef, MLP, SO3DistRef, atomic_scalars, lebedev_71, masked_softmax, normalize_alms,
+                                  sum_product_alms_ylms, to_one_hot)
+from oracle.ppo_ref import batch_indices_ref, gae_ref, loss_from_pred, normalize_adv_ref
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_g1_compute_loss_values_and_grads():
+    g = load('g1_compute_loss.npz')
+    for B in (1, 7, 140):
+        ts = [torch.tensor(g[f'B{B}_{k}'], requires_grad=True) for k in ('logp', 'ent', 'v')]
+        loss, info = loss_from_pred(*ts, torch.tensor(g[f'B{B}_old_logp']), torch.tensor(g[f'B{B}_adv']),
+                                    torch.tensor(g[f'B{B}_ret']), 0.2, 0.5, 0.01)
+        assert loss.dtype == torch.float64
+        loss.backward()
+        keys = ['policy_loss', 'entropy_loss', 'vf_loss', 'total_loss', 'approx_kl', 'clip_fraction']
+        np.testing.assert_allclose([info[k] for k in keys], g[f'B{B}_stats'], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(np.stack([t.grad.numpy() for t in ts]), g[f'B{B}_grads'], rtol=1e-6, atol=1e-12)
+
+
+def test_g2_gae_and_normalisation():
+    g = load('g2_gae.npz')
+    np.testing.assert_allclose(g['dc_y'], [1.75, 1.5, 1.0])  # tests/test_tools.py:19-26
+    for c in (0, 1):
+        off = g[f'c{c}_off']
+        adv, ret = [], []
+        for p in range(len(off) - 1):
+            a, r = gae_ref(g[f'c{c}_rew'][off[p]:off[p + 1]], g[f'c{c}_val'][off[p]:off[p + 1]], g[f'c{c}_last'][p],
+                           float(g[f'c{c}_gamma']), float(g[f'c{c}_lam']))
+            adv.append(a)
+            ret.append(r)
+        np.testing.assert_allclose(np.concatenate(adv), g[f'c{c}_adv'], rtol=1e-12)
+        np.testing.assert_allclose(np.concatenate(ret), g[f'c{c}_ret'], rtol=1e-12)
+        np.testing.assert_allclose(normalize_adv_ref(g[f'c{c}_adv']), g[f'c{c}_adv_norm'], rtol=1e-12)
+
+
+def test_g3_batch_generator():
+    g = load('g3_batches.npz')
+    for c in range(3):
+        np.random.seed(int(g[f'c{c}_seed']))
+        got = batch_indices_ref(int(g[f'c{c}_T']), int(g[f'c{c}_mb']))
+        assert len(got) == int(g[f'c{c}_n'])
+        for j, b in enumerate(got):
+            np.testing.assert_array_equal(b, g[f'c{c}_b{j}'])
+
+
+def test_g4_mlp_and_one_hot():
+    g = load('g4_mlp.npz')
+    mlp = MLP(12, (16, 5))
+    mlp.load_state_dict({k[3:]: torch.tensor(g[k]) for k in g.files if k.startswith('sd_')})
+    x = torch.tensor(g['x'], requires_grad=True)
+    y = mlp(x)
+    np.testing.assert_allclose(y.detach().numpy(), g['y'], rtol=1e-6, atol=1e-7)
+    (y * torch.linspace(-1, 1, 45).view(9, 5)).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['dx'], rtol=1e-5, atol=1e-7)
+    for k, p in mlp.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), g[f'grad_{k}'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(to_one_hot(torch.tensor(g['oh_idx']), 4).numpy(), g['oh'])
+    try:
+        to_one_hot(torch.tensor([[5]]), 4)  # tests/test_modules.py:22-29
+        raise AssertionError('out-of-range index must raise')
+    except RuntimeError:
+        pass
+
+
+def test_g5_gmm():
+    g = load('g5_gmm.npz')
+    lp = torch.tensor(g['log_probs'], requires_grad=True)
+    means = torch.tensor(g['means'], requires_grad=True)
+    ls = torch.tensor(g['log_stds'], requires_grad=True)
+    out = GMMRef(lp, means, torch.exp(ls).clamp(1e-6)).log_prob(torch.tensor(g['x']))
+    np.testing.assert_allclose(out.detach().numpy(), g['logp'], rtol=2e-6, atol=1e-6)
+    out.sum().backward()
+    np.testing.assert_allclose(lp.grad.numpy(), g['d_log_probs'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(means.grad.numpy(), g['d_means'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ls.grad.numpy(), g['d_log_stds'], rtol=1e-4, atol=1e-4)
+
+
+def test_g6_so3_tools():
+    g = load('g6_so3_tools.npz')
+    for tau in (4, 12):
+        v = so3.SO3Vec([torch.tensor(g[f't{tau}_in_{l}']) for l in range(5)])
+        np.testing.assert_allclose(atomic_scalars(v, 4).numpy(), g[f't{tau}_scalars'], rtol=1e-5, atol=1e-5)
+        n = normalize_alms(v)
+        for l in range(5):
+            np.testing.assert_allclose(n[l].numpy(), g[f't{tau}_norm_{l}'], rtol=1e-6, atol=1e-7)
+    a = so3.SO3Vec([torch.tensor(g[f'sp_a_{l}']) for l in range(5)])
+    y = so3.SO3Vec([torch.tensor(g[f'sp_y_{l}']) for l in range(5)])
+    np.testing.assert_allclose(sum_product_alms_ylms(a, y).numpy(), g['sp_out'], rtol=1e-5, atol=1e-5)
+    focus, idx = torch.tensor(g['sel_focus']), torch.tensor(g['sel_indices'])
+    for l in range(5):
+        p = torch.tensor(g[f'sel_in_{l}'])
+        sel = torch.einsum('ba,batmx->btmx', focus, p)
+        np.testing.assert_allclose(sel.numpy(), g[f'sel_cov_{l}'], rtol=1e-6)
+        got = torch.gather(sel, 1, idx.view(3, 4, 1, 1).expand(-1, -1, p.shape[-2], 2))
+        np.testing.assert_allclose(got.numpy(), g[f'sel_tau_{l}'], rtol=1e-6)
+
+
+def test_g7_spherical_distributions():
+    g = load('g7_spherical.npz')
+    a = so3.SO3Vec([torch.tensor(g[f'a_{l}']) for l in range(5)])
+    dirs = torch.tensor(g['dirs'])
+    cg = so3.CGTable(4, torch.float64)
+    for beta, tag in ((-10.0, 'm10'), (100.0, 'p100')):
+        d = SO3DistRef(a, cg, 4, beta, None)
+        np.testing.assert_allclose(d.log_z.numpy(), g[f'exp_{tag}_logz'], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(d.log_prob(dirs).numpy(), g[f'exp_{tag}_logp'], rtol=1e-4, atol=2e-4)
+    d0 = SO3DistRef(a, cg, 4, None, torch.tensor(g['so3_empty']))
+    np.testing.assert_allclose(d0.log_prob(dirs).numpy(), g['so3_logp_empty'], rtol=1e-4, atol=1e-4)
+    d1 = SO3DistRef(a, cg, 4, None, None)
+    np.testing.assert_allclose(d1.log_prob(dirs).numpy(), g['so3_logp'], rtol=1e-4, atol=1e-4)
+    pts, w = lebedev_71()
+    assert pts.shape == (1730, 3) and abs(w.sum() - 1) < 1e-12
+
+
+def test_known_answers_of_the_reference_tests():
+    g = load('known_answers.npz')
+    cg = so3.CGTable(2, torch.float32)
+    y = so3.spherical_harmonics(cg, torch.tensor(g['sph_l1_pos'], dtype=torch.float32), 1, True, False, 'qm')
+    np.testing.assert_allclose(y[1][0].numpy(), g['sph_l1'], atol=1e-6)
+    y = so3.spherical_harmonics(cg, torch.tensor(g['sph_l2_pos'], dtype=torch.float32), 2, False, False, 'qm')
+    np.testing.assert_allclose(y[2][0].numpy(), g['sph_l2'], atol=1e-6)
+    np.testing.assert_allclose(so3.cmul(torch.tensor([2., -1.]), torch.tensor([3., -2.])).numpy(), g['complex_prod'])
+    np.testing.assert_allclose(g['complex_prod'], [4., -7.])  # test_so3_tools.py:56-69
+
+
+def test_masked_softmax_known_answers():
+    """tests/test_modules.py:31-47 of the reference."""
+    logits = torch.tensor([[0.5, 0.5], [1.0, 0.5]])
+    p = masked_softmax(logits, torch.tensor([[0, 1], [1, 1]], dtype=torch.bool))
+    assert abs(p.sum().item() - 2.0) < 1e-6 and p[0, 0] == 0 and abs(p[0, 1].item() - 1) < 1e-6
+    p = masked_softmax(logits, torch.tensor([[0, 0], [1, 1]], dtype=torch.bool))
+    assert abs(p.sum().item() - 1.0) < 1e-6
