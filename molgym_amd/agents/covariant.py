@@ -60,6 +60,20 @@ class DeviceBatch:
         self.logp, self.adv, self.ret = logp, adv, ret
 
 
+class RolloutOnDevice:
+    """A parsed rollout resident in HBM; `minibatch(indices)` gathers one PPO mini-batch on the device."""
+
+    def __init__(self, ac, natoms, pos, charges, bags, actions, logp, adv, ret):
+        self.ac, self.natoms = ac, natoms
+        self.t = (pos, charges, bags, actions, logp, adv, ret)
+
+    def minibatch(self, indices: np.ndarray) -> DeviceBatch:
+        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(self.t[0].device)
+        pos, charges, bags, actions, logp, adv, ret = (x.index_select(0, idx) for x in self.t)
+        return DeviceBatch(self.ac._make_cfg(len(indices), self.natoms[indices]), pos, charges, bags, actions, logp,
+                           adv, ret)
+
+
 class _CovStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, theta, ac, cfg, pos, charges, bags, actions):
@@ -231,6 +245,20 @@ class CovariantAC(AbstractActorCritic):
         return DeviceBatch(self._make_cfg(B, natoms), torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
                            torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(logp), f64(adv),
                            f64(ret))
+
+    def prepare_rollout(self, data: Dict[str, Any]) -> 'RolloutOnDevice':
+        """Parse a whole rollout (the `data` dict of ppo.train) once; mini-batches are device gathers."""
+        N = self.observation_space.canvas_space.size
+        pos, charges, bags, natoms = parse_observations_host(data['obs'], self.zs, N)
+        acts = np.ascontiguousarray(np.asarray(data['act'], dtype=np.float32))
+        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
+        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
+            raise RuntimeError('index out of range in one-hot selection')
+        dev = self.theta.device
+        f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+        return RolloutOnDevice(self, natoms, torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
+                               torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(data['logp']),
+                               f64(data['adv']), f64(data['ret']))
 
     def _workspace(self, cfg: _lib.CovCfg) -> torch.Tensor:
         nbytes = C.c_size_t()

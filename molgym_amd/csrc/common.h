@@ -82,7 +82,7 @@ __host__ __device__ inline void ylm25(float x, float y, float z, bool nonzero, f
 
 // sqrt(4 pi / (2l+1)): 'unit' normalisation used by the relative harmonics.
 __host__ __device__ __forceinline__ float unit_norm(int l) {
-  const float t[5] = {3.5449077018110318f, 2.0466534158929770f, 1.5853309190424043f, 1.3398342629807677f,
+  const float t[5] = {3.5449077018110318f, 2.0466534158929770f, 1.5853309190424043f, 1.3398491713813576f,
                       1.1816359006036772f};
   return t[l];
 }
