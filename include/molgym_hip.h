@@ -57,6 +57,12 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 int mg_abi_version(void);
 
+/* ---- optional kernel-span timing (measurement only) ------------------------------ */
+/* on != 0: forward/backward bracket their dominant kernels with HIP events recorded on
+ * the launch stream; mg_profile_report writes "name total_ms count" lines (host buffer). */
+int mg_profile_enable(int on);
+int mg_profile_report(char* buf_host, size_t cap);
+
 /* ---- parameter vector ------------------------------------------------------------- */
 /* theta is ONE flat float32 vector.  Slot order and shapes: molgym_amd/layout.py.       */
 int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params);
@@ -74,7 +80,8 @@ int mg_cov_workspace_lookup(const mg_cov_cfg* cfg, const char* name, int64_t* of
  * charges  [B][N] i32 atomic numbers, 0 = padding
  * bags     [B][Z] f32
  * actions  [B][6] f32: focus, element index, distance, ox, oy, oz (agent.py:148-154)
- * leb      [1730][51] f32: Y_lm (25 complex, 'qm') of the Lebedev-71 points + log weight
+ * leb      [51][1730] f32, feature-major: rows 2q / 2q+1 = Re / Im of Y_q ('qm', q = l*l+l+m) at the
+ *          Lebedev-71 points, row 50 = log weight (weights sum to 1); molgym_amd/lebedev.py
  * out      [3][B] f32: logp, ent, v
  * ws       workspace of mg_cov_workspace_bytes(); keeps what backward needs.          */
 int mg_cov_forward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
@@ -102,7 +109,8 @@ int mg_gae(int32_t num_paths, const int32_t* path_off, const double* rew, const 
 int mg_adv_normalize(int32_t T, double* adv, double* scratch2, void* stream);
 
 /* ---- gradient norm + clip (util.py:61-69, ppo.py:144) ------------------------------ */
-/* norm_out[0] = ||g||_2 (f32, device).  If max_norm > 0: g *= min(1, max_norm/(norm+1e-6)). */
+/* norm_out[0] = ||g||_2 (f32, device; norm_out must hold 2 floats, [1] is scratch).
+ * If max_norm > 0: g *= min(1, max_norm/(norm+1e-6)).                                   */
 int mg_grad_norm_clip(int64_t n, float* grad, float max_norm, float* norm_out, void* stream);
 
 #ifdef __cplusplus

@@ -24,6 +24,8 @@ _P = C.c_void_p
 SYMBOLS = {
     'mg_last_error': (C.c_char_p, []),
     'mg_abi_version': (C.c_int, []),
+    'mg_profile_enable': (C.c_int, [C.c_int]),
+    'mg_profile_report': (C.c_int, [C.c_char_p, C.c_size_t]),
     'mg_cov_num_params': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64)]),
     'mg_cov_param_offsets': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'mg_cov_workspace_bytes': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_size_t)]),

@@ -23,6 +23,24 @@ static int ensure_tables() {
 }
 
 extern "C" const char* mg_last_error(void) { return g_err; }
+
+extern "C" int mg_profile_enable(int on) {
+  for (auto& sp : g_spans) { prof_flush(sp); sp.total_ms = 0; sp.count = 0; }
+  g_prof_on = on ? 1 : 0;
+  return MG_OK;
+}
+extern "C" int mg_profile_report(char* buf, size_t cap) {
+  std::string out;
+  char line[256];
+  for (auto& sp : g_spans) {
+    prof_flush(sp);
+    snprintf(line, sizeof(line), "%s %.6f %ld\n", sp.name.c_str(), sp.total_ms, sp.count);
+    out += line;
+  }
+  if (out.size() + 1 > cap) MG_FAIL(MG_ENOMEM, "profile report needs %zu bytes", out.size() + 1);
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return MG_OK;
+}
 extern "C" int mg_abi_version(void) { return 1; }
 
 extern "C" int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params) {
@@ -182,11 +200,13 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
     CatDst cd;
     for (int l = 0; l < 5; ++l) { cd.p[l] = w.cat_a[k][l]; cd.ld[l] = w.ld_a[k][l]; }
     if (k == 0) {
+      ProfScope prof(s, "k_catbuild0");
       hipLaunchKernelGGL(k_catbuild0, dim3(TA), dim3(256), 0, s, w.L, w.A0, E, w.Y, cd);
     } else {
       APtrs A;
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
+      ProfScope prof(s, "k_catbuild");
       hipLaunchKernelGGL(k_catbuild, dim3(TA), dim3(256), CB_SMEM, s, w.L, A, E, w.Y, cd);
     }
     LAUNCH_CHECK();

@@ -1,45 +1,68 @@
-"""Live kernel timing for bench.py's roofline object (HIP events on the launch stream)."""
+"""Live kernel timing for bench.py's roofline object: HIP events recorded by the library on the launch
+stream around its dominant kernels (mg_profile_enable / mg_profile_report, include/molgym_hip.h)."""
 import ctypes as C
+import json
+import os
 
 import torch
 
 from . import _lib
 
-PEAK_F32_TFLOPS = 157.3
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak == f32-input MFMA dense peak
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def time_step_stages(ac, batch, iters=20):
-    """Average device time (ms) of forward and of backward, HIP events on the current stream."""
+def kernel_spans(ac, batch, iters=20):
+    """{span name: (avg ms per launch, launches per step)} over `iters` forward+backward steps."""
     lib = _lib.lib()
-    out = ac.forward_batch(batch)
-    ws = ac._last_ws
-    gout = torch.ones_like(out) / batch.cfg.B
-    grad = torch.zeros_like(ac.theta)
-    p = lambda t: C.c_void_p(t.data_ptr())
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    torch.cuda.synchronize()
-    tf = tb = 0.0
+    lib.mg_profile_enable(1)
     for _ in range(iters):
-        ev[0].record()
-        ac.forward_batch(batch)
-        ev[1].record()
-        _lib.check(lib.mg_cov_backward(C.byref(batch.cfg), p(ac.theta), p(batch.pos), p(batch.charges), p(batch.bags),
-                                       p(batch.actions), p(ac.leb), p(ws), ws.numel(), p(gout), p(grad), stream))
-        ev[2].record()
-        torch.cuda.synchronize()
-        tf += ev[0].elapsed_time(ev[1])
-        tb += ev[1].elapsed_time(ev[2])
-    return tf / iters, tb / iters
+        ac.theta.grad = None
+        ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+    torch.cuda.synchronize()
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(lib.mg_profile_report(buf, len(buf)))
+    lib.mg_profile_enable(0)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, total, count = line.split()
+        if int(count):
+            out[name] = (float(total) / int(count), int(count) / iters)
+    return out
+
+
+def catbuild_bwd_flops(natoms):
+    """Algorithmic flops of ONE k_catbuild_bwd launch (adjoint of CG aggregate + CG power + pass-through of one
+    level >= 1 over all real atoms): 2 x the forward count of tools/flops.py for that level."""
+    L, C_ = 4, 10
+    M = [2 * l + 1 for l in range(L + 1)]
+    tot = 0
+    for n in natoms:
+        n = int(n)
+        f = 0
+        for l1 in range(L + 1):
+            for l2 in range(L + 1):
+                lo, hi = abs(l1 - l2), min(l1 + l2, L)
+                proj = C_ * M[l1] * M[l2] * sum(M[l] for l in range(lo, hi + 1)) * 4
+                f += n * (n * C_ * M[l1] * M[l2] * 8 + proj)   # aggregate: kron over n neighbours + projection
+                f += n * (C_ * M[l1] * M[l2] * 6 + proj)        # power
+        tot += 2 * f
+    return tot
 
 
 def dominant_kernel_roofline(ac, batch, natoms, cfg):
-    """Placeholder until per-kernel timing lands: device time of the whole fwd+bwd launch sequence."""
-    from tools.flops import step_flops
-    tf, tb = time_step_stages(ac, batch)
-    flops = step_flops(natoms, len(cfg['zs']))
-    achieved = flops / ((tf + tb) * 1e-3) / 1e12
+    spans = kernel_spans(ac, batch)
+    per_step = {k: v[0] * v[1] for k, v in spans.items()}
+    name = 'k_catbuild_bwd'
+    ms = spans[name][0]
+    flops = catbuild_bwd_flops(natoms)
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
     return {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_F32_TFLOPS, 'traffic': None,
-            'kernel': 'whole fwd+bwd launch sequence (f32 VALU path; f32 MFMA peak == f32 vector peak)',
-            'fwd_ms': tf, 'bwd_ms': tb}
+            'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'kernel': name,
+            'kernel_avg_ms': ms, 'launches_per_step': spans[name][1], 'algorithmic_flops_per_launch': flops,
+            'note': 'f32 VALU kernel; the f32-input MFMA dense peak equals the f32 vector peak on gfx950',
+            'span_ms_per_step': per_step}
