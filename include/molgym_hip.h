@@ -87,6 +87,13 @@ int mg_cov_workspace_lookup(const mg_cov_cfg* cfg, const char* name, int64_t* of
 int mg_cov_forward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
                    const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
                    float* out, void* stream);
+/* Rollout-side step(obs) (actions = None, agent.py:229-292): the four sub-actions are DRAWN on the device as
+ * the heads run -- mode 1 = self.training (Categorical / GMM / rejection samplers), mode 2 = evaluation
+ * (argmax variants) -- written to actions_out [B][6], and logp / ent / v of the drawn actions to out [3][B].
+ * Counter-based RNG keyed by `seed` (the torch RNG stream itself is not reproducible here).               */
+int mg_cov_sample(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
+                  const float* bags, const float* leb, uint64_t seed, int32_t mode, void* ws, size_t ws_bytes,
+                  float* actions_out, float* out, void* stream);
 /* gout [3][B] f32: dL/dlogp, dL/dent, dL/dv.  grad_theta += dL/dtheta.                 */
 int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,

@@ -32,6 +32,7 @@ SYMBOLS = {
     'mg_cov_workspace_lookup': (C.c_int, [C.POINTER(CovCfg), C.c_char_p, C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64)]),
     'mg_cov_forward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    'mg_cov_sample': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, _P, C.c_size_t, _P, _P, _P]),
     'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     'mg_gae': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),

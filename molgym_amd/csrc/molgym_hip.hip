@@ -1,6 +1,7 @@
 // molgym_hip.hip -- C-ABI entry points (include/molgym_hip.h) for the gfx950 PPO hot path.
 // One translation unit: kernels live in the .inc files next to this one.
 #include "state.inc"
+#include "sampling.inc"
 #include "backward.inc"
 #include "ppo.inc"
 
@@ -122,9 +123,14 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w) {
   return MG_OK;
 }
 
-extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
-                              const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
-                              float* out, void* stream) {
+struct SampleCtx {
+  uint64_t seed;
+  int mode;
+};
+// actions is read-only unless smp != nullptr, in which case the sub-actions are drawn in place as the heads run.
+static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
+                            const float* bags, float* actions, const float* leb, void* ws, size_t ws_bytes,
+                            float* out, void* stream, const SampleCtx* smp) {
   PLayout P;
   int rc = build_layout(c, &P);
   if (rc) return rc;
@@ -233,6 +239,11 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
     RC(launch_gemm(s, &gt, 1));
   }
   float* parts = w.parts;
+  if (smp) {
+    hipLaunchKernelGGL(k_sample_focus, dim3((B + 63) / 64), dim3(64), 0, s, B, w.L, w.logitF, smp->seed, smp->mode,
+                       actions);
+    LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_focus_head, dim3((B + 63) / 64), dim3(64), 0, s, B, w.L, w.logitF, actions, parts, parts + 4 * B,
                      w.fidx);
   LAUNCH_CHECK();
@@ -245,6 +256,13 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
     RC(launch_gemm(s, &g, 1));
     g = fwd_group(w.mlp[MLP_ELEMENT][1], theta, w.hE, W, w.logitE, Z, B, 0, nullptr);
     RC(launch_gemm(s, &g, 1));
+  }
+  if (smp) {  // draw the element, then redo the channel selection that depends on it
+    hipLaunchKernelGGL(k_sample_element, dim3((B + 63) / 64), dim3(64), 0, s, B, Z, w.logitE, bags, smp->seed,
+                       smp->mode, actions);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gather_focus, dim3(B), dim3(256), 0, s, B, Co, nlat, w.fidx, actions, w.inv, A3, w.finv, ec);
+    LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_element_head, dim3((B + 63) / 64), dim3(64), 0, s, B, Z, w.logitE, bags, actions, parts + B,
                      parts + 5 * B);
@@ -260,6 +278,11 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
     g = fwd_group(w.mlp[MLP_D][1], theta, w.hD, W, w.dout, 2 * c->G, B, 0, nullptr);
     RC(launch_gemm(s, &g, 1));
     const float half_w = (c->max_distance - c->min_distance) / 2, center = (c->max_distance + c->min_distance) / 2;
+    if (smp) {
+      hipLaunchKernelGGL(k_sample_gmm, dim3((B + 63) / 64), dim3(64), 0, s, B, c->G, w.dout, theta + P.logstd, half_w,
+                         center, smp->seed, smp->mode, actions);
+      LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_gmm, dim3((B + 63) / 64), dim3(64), 0, s, B, c->G, w.dout, theta + P.logstd, actions, half_w,
                        center, parts + 2 * B);
     LAUNCH_CHECK();
@@ -275,6 +298,11 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
     RC(launch_gemm(s, gm, 5));
     CondPtrs cp;
     for (int l = 0; l < 5; ++l) cp.p[l] = w.cond[l];
+    if (smp) {
+      hipLaunchKernelGGL(k_sample_so3, dim3(B), dim3(256), 0, s, B, w.L, cp, c->has_beta, c->beta, smp->seed, smp->mode,
+                         actions);
+      LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_so3, dim3(B), dim3(256), 0, s, B, w.L, cp, actions, leb, c->has_beta, c->beta, parts + 3 * B,
                        w.logz);
     LAUNCH_CHECK();
@@ -291,4 +319,20 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
   LAUNCH_CHECK();
 #undef RC
   return MG_OK;
+}
+
+extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
+                              const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
+                              float* out, void* stream) {
+  return cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream,
+                          nullptr);
+}
+
+extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
+                             const float* bags, const float* leb, uint64_t seed, int32_t mode, void* ws,
+                             size_t ws_bytes, float* actions_out, float* out, void* stream) {
+  if (mode != SAMPLE_TRAIN && mode != SAMPLE_EVAL) MG_FAIL(MG_EINVAL, "mode must be 1 (sample) or 2 (argmax)");
+  HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
+  SampleCtx smp = {seed, mode};
+  return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
 }
