@@ -99,6 +99,33 @@ int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
                     const float* gout, float* grad_theta, void* stream);
 
+/* ---- internal-coordinate agent: SchNetAC.step(obs, actions), molgym/agents/internal/agent.py:181-353 ----
+ * The schnetpack SchNet embedding is evaluated once over 3B molecules: set 0 = the canvases (n_b atoms), sets 1
+ * and 2 = canvas + the new atom placed by zmat.position_atom_helper (internal/zmat.py:96-133, done on the host
+ * in float64) at +dihedral / -dihedral.  Molecule m = set * B + b.
+ *   mol_off  [3B+1] i32 atom offsets, edge_off [3B+1] i32 ordered-pair offsets (n(n-1) per molecule),
+ *   molZ [MA] i32 atomic numbers, molpos [MA][3] f32, bags [B][Z] f32,
+ *   actions [B][7] f32: stop, focus, element, distance, angle, dihedral, kappa (agent.py:26,306-308)
+ *   out [3][B] f32: logp (masked sum), ent (focus + element), v.                                            */
+typedef struct mg_int_cfg {
+  int32_t B, N, Z;
+  int32_t zs[MG_MAX_Z];
+  int32_t W;          /* network_width, multiple of 16                                 */
+  int32_t TA;         /* real atoms on the canvases                                    */
+  int32_t MA;         /* atoms over all 3B molecules = 3*TA + 2*B                      */
+  int32_t ME;         /* ordered pairs over all 3B molecules                           */
+  float min_distance, max_distance;
+} mg_int_cfg;
+int mg_int_num_params(const mg_int_cfg* cfg, int64_t* num_params);
+int mg_int_param_offsets(const mg_int_cfg* cfg, int64_t* offsets_out_host, int32_t* n_slots_host);
+int mg_int_workspace_bytes(const mg_int_cfg* cfg, size_t* bytes_host);
+int mg_int_forward(const mg_int_cfg* cfg, const float* theta, const int32_t* mol_off, const int32_t* edge_off,
+                   const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* ws,
+                   size_t ws_bytes, float* out, void* stream);
+int mg_int_backward(const mg_int_cfg* cfg, const float* theta, const int32_t* mol_off, const int32_t* edge_off,
+                    const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* ws,
+                    size_t ws_bytes, const float* gout, float* grad_theta, void* stream);
+
 /* ---- PPO loss, float64 (ppo.py:28-52) --------------------------------------------- */
 /* pred [3][B] f32 (logp, ent, v); old_logp, adv, ret [B] f64.
  * stats[6] f64: policy_loss, entropy_loss, vf_loss, total_loss, approx_kl, clip_fraction.

@@ -19,6 +19,14 @@ class CovCfg(C.Structure):
     ]
 
 
+class IntCfg(C.Structure):
+    _fields_ = [
+        ('B', C.c_int32), ('N', C.c_int32), ('Z', C.c_int32), ('zs', C.c_int32 * MG_MAX_Z), ('W', C.c_int32),
+        ('TA', C.c_int32), ('MA', C.c_int32), ('ME', C.c_int32), ('min_distance', C.c_float),
+        ('max_distance', C.c_float),
+    ]
+
+
 # every symbol include/molgym_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -34,6 +42,11 @@ SYMBOLS = {
     'mg_cov_forward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
     'mg_cov_sample': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, _P, C.c_size_t, _P, _P, _P]),
     'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
+    'mg_int_num_params': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_int64)]),
+    'mg_int_param_offsets': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    'mg_int_workspace_bytes': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_size_t)]),
+    'mg_int_forward': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
+    'mg_int_backward': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     'mg_gae': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     'mg_adv_normalize': (C.c_int, [C.c_int32, _P, _P, _P]),

@@ -1,0 +1,184 @@
+"""Internal-coordinate (SchNet) actor-critic on the gfx950 HIP kernels.
+
+Drop-in for /root/reference/molgym/agents/internal/agent.py:17-353: same constructor keywords
+(model_util.py:18-24), same ``step(observations, actions)`` contract with the 7-column action rows
+``[stop, focus, element, distance, angle, dihedral, kappa]`` (agent.py:26,306-308).  The reference runs the
+schnetpack SchNet embedding 3*B times per call at batch size 1 (agent.py:128,177); here the host builds ONE
+ragged batch of 3B molecules -- the canvases and the canvases plus the hypothetical new atom at +/- dihedral,
+placed by the z-matrix helper (internal/zmat.py:66-133, float64 numpy, no gradient, as in the reference which
+goes through ``to_numpy``) -- and the whole step is two C-ABI calls.
+"""
+import ctypes as C
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib, layout
+from ..spaces import ActionSpace, ObservationSpace, ObservationType
+from .base import AbstractActorCritic
+from .covariant import _ptr, _stream, parse_observations_host
+
+
+def place_new_atoms(pos: np.ndarray, natoms: np.ndarray, focus: np.ndarray, distance, angle, dihedral) -> np.ndarray:
+    """Vectorised zmat.position_atom_helper: pos (B, N, 3) float64 (real atoms first) -> new positions (B, 3)."""
+    B, N, _ = pos.shape
+    out = np.zeros((B, 3))
+    if np.any((focus >= natoms) & (natoms > 0)) or np.any(focus < 0):
+        raise RuntimeError('Focus greater than number of atoms')
+    nz = np.nonzero(natoms > 0)[0]
+    if len(nz) == 0:
+        return out
+    p, n, f = pos[nz], natoms[nz], focus[nz]
+    fpos = p[np.arange(len(nz)), f]
+    dist = np.sqrt(np.sum(np.square(p - fpos[:, None, :]), axis=-1))
+    dist = np.where(np.arange(N)[None, :] < n[:, None], dist, np.inf)
+    order = np.argsort(dist, axis=1, kind='stable')  # sorted() in the reference is stable too
+    rows = np.arange(len(nz))
+    p2 = p[rows, order[:, 0]]
+    p1 = np.where((n >= 2)[:, None], p[rows, order[:, min(1, N - 1)]], p2 + np.array([1.0, 0.0, 0.0]))
+    p0_three = p[rows, order[:, min(2, N - 1)]]
+    p0 = np.where((n >= 3)[:, None], p0_three,
+                  np.where((n == 2)[:, None], p2 + p1 + np.array([1.0, 1.0, 0.0]), p2 + np.array([0.0, 1.0, 0.0])))
+    d, a, h = distance[nz, None], angle[nz, None], dihedral[nz, None]
+    x, y, z = d * np.cos(a), d * np.cos(h) * np.sin(a), d * np.sin(h) * np.sin(a)
+    v_a = p1 - p0
+    v_b = p2 - p1
+    v_b = v_b / np.linalg.norm(v_b, axis=1, keepdims=True)
+    c_ab = np.cross(v_a, v_b)
+    c_ab = c_ab / np.linalg.norm(c_ab, axis=1, keepdims=True)
+    c_ab_b = np.cross(c_ab, v_b)
+    out[nz] = p2 - v_b * x + c_ab_b * y + c_ab * z
+    return out
+
+
+class IntBatch:
+    def __init__(self, cfg, mol_off, edge_off, molZ, molpos, bags, actions):
+        self.cfg, self.mol_off, self.edge_off, self.molZ, self.molpos = cfg, mol_off, edge_off, molZ, molpos
+        self.bags, self.actions = bags, actions
+
+
+class _IntStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, ac, batch):
+        lib = _lib.lib()
+        nbytes = C.c_size_t()
+        _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=theta.device)
+        out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=theta.device)
+        _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
+                                      _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
+                                      _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        ctx.save_for_backward(theta, ws)
+        ctx.batch = batch
+        ac._last_ws = ws
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        theta, ws = ctx.saved_tensors
+        b = ctx.batch
+        grad = torch.zeros_like(theta)
+        gout = gout.contiguous()
+        _lib.check(_lib.lib().mg_int_backward(C.byref(b.cfg), _ptr(theta), _ptr(b.mol_off), _ptr(b.edge_off),
+                                              _ptr(b.molZ), _ptr(b.molpos), _ptr(b.bags), _ptr(b.actions), _ptr(ws),
+                                              ws.numel(), _ptr(gout), _ptr(grad), _stream()))
+        return grad, None, None
+
+
+class SchNetAC(AbstractActorCritic):
+    def __init__(self, observation_space: ObservationSpace, action_space: ActionSpace,
+                 min_max_distance: Tuple[float, float], network_width: int, device=None):
+        super().__init__(observation_space, action_space)
+        self.device = torch.device(device) if device is not None else torch.device('cuda')
+        self.zs = list(self.observation_space.zs)
+        self.num_atoms = self.observation_space.canvas_space.size
+        self.num_zs = len(self.zs)
+        self.network_width = network_width
+        self.min_distance, self.max_distance = min_max_distance
+        self.slot_table, total = layout.offsets_internal(self.num_zs, network_width)
+        self.theta = torch.nn.Parameter(self._init_theta(total))
+        self._last_ws = None
+        self.to(self.device)
+
+    def _init_theta(self, total: int) -> torch.Tensor:
+        """schnetpack initialisers (Embedding N(0,1) with a zero padding row, Dense = xavier_uniform + zero
+        bias), orthogonal MLPs with zero bias (modules.py:30-34), log stds of agent.py:69-70."""
+        theta = torch.zeros(total)
+        for name, (off, shape) in self.slot_table.items():
+            n = int(np.prod(shape))
+            view = theta[off:off + n].view(shape)
+            if name == 'embedding_fn.embedding.weight':
+                view.normal_()
+                view[0].zero_()
+            elif name.startswith('embedding_fn') and name.endswith('weight'):
+                torch.nn.init.xavier_uniform_(view)
+            elif name == 'log_stds':
+                view.copy_(torch.log(torch.tensor([0.15, 0.25, 0.25])))
+            elif name.endswith('weight'):
+                torch.nn.init.orthogonal_(view)
+            # every bias starts at zero
+        return theta
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        t = self.theta.detach()
+        return {k: t[o:o + int(np.prod(s))].view(s).clone() for k, (o, s) in self.slot_table.items()}
+
+    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad():
+            for k, (o, s) in self.slot_table.items():
+                self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
+
+    def make_batch(self, observations: List[ObservationType], actions: np.ndarray) -> IntBatch:
+        N, B = self.num_atoms, len(observations)
+        pos32, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
+        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
+        assert acts.shape == (B, 7)
+        focus, element = np.rint(acts[:, 1]).astype(np.int64), np.rint(acts[:, 2]).astype(np.int64)
+        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= self.num_zs:
+            raise RuntimeError('index out of range in one-hot selection')
+        # exact float64 positions for the z-matrix step, as the reference (ase.Atoms positions are float64)
+        pos64 = np.zeros((B, N, 3))
+        for b, (canvas, _) in enumerate(observations):
+            k = 0
+            for label, xyz in canvas:
+                if self.zs[label] != 0:
+                    pos64[b, k] = xyz
+                    k += 1
+        a64 = np.asarray(actions, dtype=np.float32).astype(np.float64)  # the agent casts actions to its dtype
+        new_p = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], a64[:, 5])
+        new_m = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], -a64[:, 5])
+        z_new = np.asarray(self.zs, dtype=np.int32)[element]
+        real = np.arange(N)[None, :] < natoms[:, None]
+        base_z, base_p = charges[real], pos64[real]
+        TA = int(natoms.sum())
+        sizes = np.concatenate([natoms, natoms + 1, natoms + 1]).astype(np.int64)
+        mol_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        edge_off = np.concatenate([[0], np.cumsum(sizes * (sizes - 1))]).astype(np.int32)
+        MA = int(mol_off[-1])
+        molZ, molpos = np.zeros(MA, dtype=np.int32), np.zeros((MA, 3))
+        molZ[:TA], molpos[:TA] = base_z, base_p
+        atom_b = np.repeat(np.arange(B), natoms)
+        local = np.arange(TA) - np.repeat(np.cumsum(natoms) - natoms, natoms)
+        for s, new in ((1, new_p), (2, new_m)):
+            start = mol_off[s * B:(s + 1) * B].astype(np.int64)
+            molZ[start[atom_b] + local], molpos[start[atom_b] + local] = base_z, base_p
+            molZ[start + natoms], molpos[start + natoms] = z_new, new
+        cfg = _lib.IntCfg()
+        cfg.B, cfg.N, cfg.Z, cfg.W = B, N, self.num_zs, self.network_width
+        for i, z in enumerate(self.zs):
+            cfg.zs[i] = int(z)
+        cfg.TA, cfg.MA, cfg.ME = TA, MA, int(edge_off[-1])
+        cfg.min_distance, cfg.max_distance = float(self.min_distance), float(self.max_distance)
+        dev = self.theta.device
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        return IntBatch(cfg, t(mol_off), t(edge_off), t(molZ), t(molpos.astype(np.float32)), t(bags), t(acts))
+
+    def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
+        if self.theta.device.type != 'cuda':
+            raise RuntimeError('SchNetAC runs on the HIP device only (no CPU fallback)')
+        if actions is None:
+            raise NotImplementedError('rollout-side sampling of the internal agent is not on the device yet')
+        batch = self.make_batch(observations, actions)
+        out = _IntStep.apply(self.theta, self, batch)
+        return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2]}

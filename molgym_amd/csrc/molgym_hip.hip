@@ -4,6 +4,7 @@
 #include "sampling.inc"
 #include "backward.inc"
 #include "ppo.inc"
+#include "internal.inc"
 
 static bool g_tables_ready = false;
 static int ensure_tables() {

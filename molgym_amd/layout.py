@@ -69,3 +69,52 @@ def offsets(num_zs: int, width: int, num_gaussians: int):
         out[name] = (off, shape)
         off += n
     return out, off
+
+
+# ---- internal-coordinate agent (SchNetAC) -----------------------------------------------------------------
+SN_F, SN_G, SN_MAXZ, SN_T = 128, 25, 100, 3
+
+
+def slots_internal(num_zs: int, width: int) -> 'OrderedDict[str, Tuple[int, ...]]':
+    """state_dict-style names of /root/reference/molgym/agents/internal/agent.py:37-105 (the schnetpack 0.3
+    SchNet module tree under `embedding_fn`; its filter_network is also aliased under cfconv there)."""
+    af, lb = width // 2, width // 4
+    nl = af + lb
+    s: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
+    s['embedding_fn.embedding.weight'] = (SN_MAXZ, af)
+    for t in range(SN_T):
+        b = f'embedding_fn.interactions.{t}'
+        s[f'{b}.filter_network.0.weight'] = (SN_F, SN_G)
+        s[f'{b}.filter_network.0.bias'] = (SN_F, )
+        s[f'{b}.filter_network.1.weight'] = (SN_F, SN_F)
+        s[f'{b}.filter_network.1.bias'] = (SN_F, )
+        s[f'{b}.cfconv.in2f.weight'] = (SN_F, af)
+        s[f'{b}.cfconv.f2out.weight'] = (af, SN_F)
+        s[f'{b}.cfconv.f2out.bias'] = (af, )
+        s[f'{b}.dense.weight'] = (af, af)
+        s[f'{b}.dense.bias'] = (af, )
+    for name, n_in, n_out in (('phi_beta', num_zs, lb), ('phi_focus', nl, 1), ('phi_element', nl, num_zs),
+                              ('phi_continuous', nl + num_zs, 3), ('phi_kappa', nl, 1)):
+        s[f'{name}.layers.0.weight'] = (width, n_in)
+        s[f'{name}.layers.0.bias'] = (width, )
+        s[f'{name}.layers.1.weight'] = (n_out, width)
+        s[f'{name}.layers.1.bias'] = (n_out, )
+    s['log_stds'] = (3, )
+    s['critic.layers.0.weight'] = (width, nl)
+    s['critic.layers.0.bias'] = (width, )
+    s['critic.layers.1.weight'] = (width, width)
+    s['critic.layers.1.bias'] = (width, )
+    s['critic.layers.2.weight'] = (1, width)
+    s['critic.layers.2.bias'] = (1, )
+    return s
+
+
+def offsets_internal(num_zs: int, width: int):
+    out, off = OrderedDict(), 0
+    for name, shape in slots_internal(num_zs, width).items():
+        n = 1
+        for d in shape:
+            n *= d
+        out[name] = (off, shape)
+        off += n
+    return out, off

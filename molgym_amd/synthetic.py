@@ -74,3 +74,18 @@ def make_batch(batch: int, canvas_size: int, zs: Sequence[int], seed: int = 0) -
     adv = (adv - adv.mean()) / adv.std()
     return dict(obs=obs, act=act, logp=rng.normal(-5.0, 1.0, size=batch), adv=adv,
                 ret=rng.normal(0.0, 0.3, size=batch))
+
+
+def make_batch_internal(batch: int, canvas_size: int, zs: Sequence[int], seed: int = 0) -> Dict[str, object]:
+    """Same canvases, with the 7-column internal-coordinate actions of SchNetAC
+    (stop, focus, element, distance, angle, dihedral, kappa; internal/agent.py:26,306-308)."""
+    d = make_batch(batch, canvas_size, zs, seed)
+    rng = np.random.default_rng(seed + 1000)
+    a6 = d['act']
+    act = np.zeros((batch, 7), dtype=np.float64)
+    act[:, 1], act[:, 2], act[:, 3] = a6[:, 0], a6[:, 1], a6[:, 2]
+    act[:, 4] = rng.uniform(0.3, np.pi - 0.3, size=batch)
+    act[:, 5] = rng.uniform(0.2, np.pi - 0.2, size=batch)
+    act[:, 6] = rng.integers(0, 2, size=batch)
+    d['act'] = act
+    return d

@@ -252,6 +252,21 @@ def main():
              sph_l2=np.array([[0, -0.289706], [0.236544, -0.236544], [-0.0788479, 0], [-0.236544, -0.236544],
                               [0, 0.289706]]),  # test_sphs.py:46-53
              complex_prod=so3_tools.complex_product(torch.tensor([2., -1.]), torch.tensor([3., -2.])).numpy())
+    # ---- G8 z-matrix placement (internal/zmat.py) ------------------------------------------------
+    from molgym.agents.internal import zmat
+    g8 = {}
+    for n in (0, 1, 2, 3, 5):
+        pos = [rng.normal(size=3) * 1.5 for _ in range(n)]
+        focus = int(rng.integers(0, max(n, 1)))
+        d, ang, dih = float(rng.uniform(0.9, 1.8)), float(rng.uniform(0.3, 2.8)), float(rng.uniform(-3.0, 3.0))
+        g8[f'n{n}_pos'] = np.array(pos).reshape(n, 3)
+        g8[f'n{n}_args'] = np.array([focus, d, ang, dih])
+        g8[f'n{n}_out'] = zmat.position_atom_helper(positions=pos, focus=focus, distance=d, angle=ang, dihedral=dih)
+    p = [rng.normal(size=3) for _ in range(4)]
+    g8['geo_pts'] = np.array(p)
+    g8['geo'] = np.array([zmat.get_distance(p[0], p[1]), zmat.get_angle(p[0], p[1], p[2]),
+                          zmat.get_dihedral(p[0], p[1], p[2], p[3])])
+    np.savez(os.path.join(OUT, 'g8_zmat.npz'), **g8)
     print('golden fixtures written to', OUT)
 
 
