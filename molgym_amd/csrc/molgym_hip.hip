@@ -291,7 +291,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   {
     CatDst cm;
     for (int l = 0; l < 5; ++l) { cm.p[l] = w.cat_m[l]; cm.ld[l] = w.ld_m[l]; }
-    hipLaunchKernelGGL(k_mixer_cat, dim3((B * CE * NLM + 127) / 128), dim3(128), 0, s, B, actions, ec, cm);
+    hipLaunchKernelGGL(k_mixer_cat, dim3((B * CE * (CG_NROWS + NLM) + 255) / 256), dim3(256), 0, s, B, actions, ec, cm);
     LAUNCH_CHECK();
     GemmG gm[5];
     for (int l = 0; l < 5; ++l)
