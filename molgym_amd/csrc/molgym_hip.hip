@@ -2,6 +2,7 @@
 // One translation unit: kernels live in the .inc files next to this one.
 #include "state.inc"
 #include "sampling.inc"
+#include "heads_fused.inc"
 #include "backward.inc"
 #include "ppo.inc"
 #include "internal.inc"
@@ -228,6 +229,21 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   APtrs A3;
   for (int l = 0; l < 5; ++l) A3.p[l] = w.A[3][l];
   A3.C = Co;
+  if (!smp && !use_staged_heads()) {  // action evaluation: all heads in one launch (heads_fused.inc)
+    if (TA > 0) {
+      hipLaunchKernelGGL(k_scalars, dim3((TA * Co + 255) / 256), dim3(256), 0, s, TA, Co, A3, w.inv);
+      LAUNCH_CHECK();
+    }
+    HeadDims HD;
+    HeadW HW;
+    HeadBuf HB;
+    make_head_args(c, P, w, theta, &HD, &HW, &HB);
+    ProfScope prof(s, "k_heads_fwd");
+    hipLaunchKernelGGL(k_heads_fwd, dim3(B), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, A3, actions,
+                       bags, leb, out);
+    LAUNCH_CHECK();
+    return MG_OK;
+  }
   if (TA > 0) {
     hipLaunchKernelGGL(k_scalars, dim3((TA * Co + 255) / 256), dim3(256), 0, s, TA, Co, A3, w.inv);
     LAUNCH_CHECK();
