@@ -138,6 +138,13 @@ class CovariantAC(AbstractActorCritic):
         self._last_ws = None
         self.to(self.device)
 
+    # whole-module pickling (ModelIO.save = torch.save(module), tools/model_util.py:82-91): drop the caches
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_last_ws'] = None
+        state.pop('_ws_cache', None)
+        return state
+
     # -- parameters -----------------------------------------------------------------------------
     def _init_theta(self, total: int) -> torch.Tensor:
         """Same initialisers as the reference stack: torch Linear defaults for the radial / input

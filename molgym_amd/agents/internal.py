@@ -101,6 +101,11 @@ class SchNetAC(AbstractActorCritic):
         self._last_ws = None
         self.to(self.device)
 
+    def __getstate__(self):  # whole-module pickling (tools/model_util.py:82-91): drop the workspace cache
+        state = self.__dict__.copy()
+        state['_last_ws'] = None
+        return state
+
     def _init_theta(self, total: int) -> torch.Tensor:
         """schnetpack initialisers (Embedding N(0,1) with a zero padding row, Dense = xavier_uniform + zero
         bias), orthogonal MLPs with zero bias (modules.py:30-34), log stds of agent.py:69-70."""

@@ -121,3 +121,19 @@ def test_bad_indices_raise(built_lib):
     act[1, 1] = len(cfg['zs'])
     with pytest.raises(RuntimeError):
         ac.step(data['obs'], act)
+
+
+def test_whole_module_pickle_round_trip(built_lib, tmp_path):
+    """ModelIO saves the whole nn.Module with torch.save (tools/model_util.py:82-100); the agent must survive it."""
+    ac, ref, cfg = make_pair('cfg2', seed=14)
+    data = make_batch(5, cfg['canvas_size'], cfg['zs'], seed=2)
+    with torch.no_grad():
+        before = ac.step(data['obs'], data['act'])['logp'].cpu()
+    path = str(tmp_path / 'agent.model')
+    torch.save(ac, path)
+    assert __import__('os').path.getsize(path) < 4 * 1024 * 1024  # parameters only, no workspace
+    again = torch.load(path, weights_only=False)
+    again.observation_space, again.action_space = ac.observation_space, ac.action_space  # run.py:53-54
+    with torch.no_grad():
+        after = again.step(data['obs'], data['act'])['logp'].cpu()
+    assert torch.equal(before, after)
