@@ -28,6 +28,7 @@ def parse_args():
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--config', default='cfg2', help='synthetic workload (molgym_amd/synthetic.py)')
     p.add_argument('--batch', type=int, default=None, help='override the mini-batch size per GPU')
+    p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
     return p.parse_args()
@@ -137,15 +138,33 @@ def main():
     ac.theta.grad = torch.zeros_like(ac.theta)
     inv_world = 1.0 / world
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
+    counter = [0]
+
     def step():
-        ac.theta.grad.zero_()
-        stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world)
-        if world > 1:
-            dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
-        return stats
+        if streams is None:
+            ac.theta.grad.zero_()
+            stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world)
+            if world > 1:
+                dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
+            return stats
+        # epoch semantics of ppo.train: gradients of independent mini-batches accumulate; they are issued
+        # round-robin on `inflight` streams with their own workspaces
+        k = counter[0] % len(streams)
+        counter[0] += 1
+        with torch.cuda.stream(streams[k]):
+            return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world, slot=k)
+
+    def drain():
+        if streams is not None:
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            if world > 1:
+                dist.all_reduce(ac.theta.grad)
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -153,6 +172,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -182,7 +202,7 @@ def main():
             'config': {'workload': f'{args.config}: covariant actor-critic, zs={cfg["zs"]}, canvas_size='
                                    f'{cfg["canvas_size"]}, mini_batch={B} per GPU, beta={cfg["beta"]}, random-walk '
                                    f'canvases with U{{0..N}} atoms, inputs resident in HBM',
-                       'global_batch': world * B, 'parallelism': f'dp{world}',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'minibatches_in_flight': args.inflight,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,
                        'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world)},

@@ -267,18 +267,19 @@ class CovariantAC(AbstractActorCritic):
                                torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(data['logp']),
                                f64(data['adv']), f64(data['ret']))
 
-    def _workspace(self, cfg: _lib.CovCfg) -> torch.Tensor:
+    def _workspace(self, cfg: _lib.CovCfg, slot: int = 0) -> torch.Tensor:
         nbytes = C.c_size_t()
         _lib.check(_lib.lib().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
-        ws = getattr(self, '_ws_cache', None)
+        cache = self.__dict__.setdefault('_ws_cache', {})
+        ws = cache.get(slot)
         if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
             ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
-            self._ws_cache = ws
+            cache[slot] = ws
         return ws
 
-    def forward_batch(self, batch: 'DeviceBatch') -> torch.Tensor:
+    def forward_batch(self, batch: 'DeviceBatch', slot: int = 0) -> torch.Tensor:
         """(3, B) float32: logp, ent, v -- no autograd graph."""
-        ws = self._workspace(batch.cfg)
+        ws = self._workspace(batch.cfg, slot)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
         _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
                                              _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
@@ -287,12 +288,13 @@ class CovariantAC(AbstractActorCritic):
         return out
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
-                      loss_scale: float = 1.0) -> torch.Tensor:
+                      loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
         """One compute_loss forward + backward (molgym/ppo.py:124-131) entirely on the device:
-        step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED into theta.grad.
-        Returns the 6 float64 loss statistics (device tensor, no sync)."""
+        step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED (atomically) into theta.grad.
+        Returns the 6 float64 loss statistics (device tensor, no sync).  `slot` selects an independent workspace,
+        so the mini-batches of one epoch -- independent given theta -- can be in flight on several HIP streams."""
         lib = _lib.lib()
-        out = self.forward_batch(batch)
+        out = self.forward_batch(batch, slot)
         ws = self._last_ws
         B = batch.cfg.B
         stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
@@ -307,28 +309,6 @@ class CovariantAC(AbstractActorCritic):
                                        _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
                                        _ptr(gout), _ptr(self.theta.grad), _stream()))
         return stats
-
-    def _step_sample(self, observations: List[ObservationType]) -> Dict[str, Any]:
-        """step(obs) of the rollout (agent.py:229-292, ppo.py:188,205): draw the sub-actions on the device
-        (training) or take the argmax variants (evaluation) and return logp / ent / v of what was drawn."""
-        N = self.observation_space.canvas_space.size
-        pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
-        B = len(observations)
-        cfg = self._make_cfg(B, natoms)
-        dev = self.theta.device
-        d_pos, d_chg, d_bag = (torch.from_numpy(x).to(dev) for x in (pos, charges, bags))
-        ws = self._workspace(cfg)
-        out = torch.empty(3, B, dtype=torch.float32, device=dev)
-        acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
-        seed = int(torch.randint(0, 2**62, (1, )).item())  # follows torch.manual_seed (util.set_seeds)
-        mode = 1 if self.training else 2
-        _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
-                                            _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(), _ptr(acts),
-                                            _ptr(out), _stream()))
-        self._last_ws = ws
-        host = acts.cpu().numpy()
-        return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
-                'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
 
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""

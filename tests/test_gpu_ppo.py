@@ -121,3 +121,30 @@ def test_train_loop_matches_oracle_loop(built_lib):
     for k, v in ref.state_dict().items():
         d = (new[k].double().cpu() - v).abs().max().item()
         assert d < 1e-4, (k, d)  # two Adam steps of lr 3e-4
+
+
+def test_minibatches_in_flight_accumulate_like_sequential(built_lib):
+    """three mini-batches on three HIP streams (own workspaces, atomic accumulation) == the sequential sum"""
+    ac, ref, cfg = make_pair('cfg2', seed=23)
+    batches = []
+    for k in range(3):
+        d = make_batch(20 + 5 * k, cfg['canvas_size'], cfg['zs'], seed=30 + k)
+        batches.append(ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret']))
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    seq_stats = [ac.ppo_minibatch(b, 0.2, 0.5, 0.01).clone() for b in batches]
+    torch.cuda.synchronize()
+    g_seq = ac.theta.grad.clone()
+    ac.theta.grad.zero_()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    par_stats = []
+    for k, b in enumerate(batches):
+        streams[k].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[k]):
+            par_stats.append(ac.ppo_minibatch(b, 0.2, 0.5, 0.01, slot=k))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    scale = g_seq.abs().max().item()
+    assert (ac.theta.grad - g_seq).abs().max().item() < 1e-5 * scale
+    for a, b in zip(seq_stats, par_stats):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-12)
