@@ -310,6 +310,28 @@ class CovariantAC(AbstractActorCritic):
                                        _ptr(gout), _ptr(self.theta.grad), _stream()))
         return stats
 
+    def _step_sample(self, observations: List[ObservationType]) -> Dict[str, Any]:
+        """step(obs) of the rollout (agent.py:229-292, ppo.py:188,205): draw the sub-actions on the device
+        (training) or take the argmax variants (evaluation) and return logp / ent / v of what was drawn."""
+        N = self.observation_space.canvas_space.size
+        pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
+        B = len(observations)
+        cfg = self._make_cfg(B, natoms)
+        dev = self.theta.device
+        d_pos, d_chg, d_bag = (torch.from_numpy(x).to(dev) for x in (pos, charges, bags))
+        ws = self._workspace(cfg)
+        out = torch.empty(3, B, dtype=torch.float32, device=dev)
+        acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
+        seed = int(torch.randint(0, 2**62, (1, )).item())  # follows torch.manual_seed (util.set_seeds)
+        mode = 1 if self.training else 2
+        _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
+                                            _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(), _ptr(acts),
+                                            _ptr(out), _stream()))
+        self._last_ws = ws
+        host = acts.cpu().numpy()
+        return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
+                'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
+
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""
         off, cnt = C.c_int64(), C.c_int64()
