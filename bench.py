@@ -173,6 +173,7 @@ def main():
     for _ in range(args.steps):
         stats = step()
     drain()
+    t_issued = time.perf_counter() - t0  # host time to enqueue the K steps (diagnostic: CPU-bound if ~= elapsed)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,6 +204,7 @@ def main():
                                    f'{cfg["canvas_size"]}, mini_batch={B} per GPU, beta={cfg["beta"]}, random-walk '
                                    f'canvases with U{{0..N}} atoms, inputs resident in HBM',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'minibatches_in_flight': args.inflight,
+                       'host_enqueue_ms_per_step': t_issued / args.steps * 1e3,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,
                        'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world)},

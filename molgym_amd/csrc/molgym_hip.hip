@@ -162,6 +162,18 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
                        (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]), soft_rad, soft_width, go);
     LAUNCH_CHECK();
   }
+  if (TE > 0 && TA > 0) {
+    // the radial Linears of all three levels depend on the geometry only: side stream, beside the input Linear
+    // and the first DotMatrix (they fill the radial columns of cat_e[k]; joined before the first edge cat-mix)
+    hipStream_t ss = side_fork(s);
+    for (int k = 0; k < 3; ++k) {
+      GemmG gr[5];
+      for (int l = 0; l < 5; ++l)
+        gr[l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE, 0,
+                          nullptr);
+      RC(launch_gemm(ss, gr, 5));
+    }
+  }
   if (TA > 0) {
     hipLaunchKernelGGL(k_atom_scalars, dim3((TA * 4 * Z + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
                        c->bag_scale, charges, bags, w.L, w.scal);
@@ -185,14 +197,13 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       hipLaunchKernelGGL(k_dot, dim3((TE * 50 + 255) / 256), dim3(256), 0, s, TE, w.L, A, d);
     }
     LAUNCH_CHECK();
-    GemmG gr[5], ge[5];
+    GemmG ge[5];
     for (int l = 0; l < 5; ++l) {
-      gr[l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE, 0, nullptr);
       float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
       const int ldE = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
       ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
     }
-    RC(launch_gemm(s, gr, 5));
+    if (k == 0) side_join(s);  // radial columns of every level are in place
     if (k == 0) {  // l = 0 has a different reduction width (and tile alignment) than l >= 1
       RC(launch_gemm(s, ge, 1));
       RC(launch_gemm(s, ge + 1, 4));
