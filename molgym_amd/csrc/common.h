@@ -12,6 +12,18 @@
 #define NLEB 1730
 #define LEB_STRIDE 51
 
+// phase timestamps inside a kernel (debug builds only: -DMG_TS; tools/ts_heads.sh)
+#ifndef MG_EXP
+#define MG_EXP 0
+#endif
+#ifdef MG_TS
+__device__ unsigned long long g_ts[64];
+__device__ int g_ts_block;
+#define TS(i) do { if (blockIdx.x == g_ts_block && blockIdx.y == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
+#else
+#define TS(i) do { } while (0)
+#endif
+
 struct cf {  // complex float
   float r, i;
 };

@@ -364,3 +364,13 @@ extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const floa
   SampleCtx smp = {seed, mode};
   return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
 }
+
+#ifdef MG_TS
+// debug builds only (tools/ts_heads.sh): read the phase timestamps (100 MHz ticks) and choose the stamped workgroup
+extern "C" int mg_debug_ts(unsigned long long* out, int block) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 64));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_block), &block, sizeof(int)));
+  return MG_OK;
+}
+#endif
