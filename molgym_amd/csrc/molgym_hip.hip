@@ -20,6 +20,7 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_l), h_cgT_l, sizeof(h_cgT_l)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_blk), h_cgT_blk, sizeof(h_cgT_blk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_c), h_cgT_c, sizeof(h_cgT_c)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_key), h_cgT_key, sizeof(h_cgT_key)));
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready = true;
   return MG_OK;

@@ -27,8 +27,10 @@ def main():
     lib = _lib.lib()
     lib.mg_debug_ts.argtypes = [C.c_void_p, C.c_int]
     buf = (C.c_ulonglong * 64)()
-    for target in (max(natoms), int(np.median(natoms))):
-        blk = natoms.index(target)
+    for target in (max(natoms), int(np.median(natoms)), -max(natoms)):
+        blk = natoms.index(abs(target))
+        if target < 0:  # stamp the first ATOM of that sample (k_catbuild_bwd is one workgroup per atom)
+            blk = int(sum(natoms[:blk]))
         lib.mg_debug_ts(buf, blk)
         for _ in range(3):
             ac.theta.grad = None
@@ -36,6 +38,7 @@ def main():
         lib.mg_debug_ts(buf, blk)
         ts = np.array(list(buf), dtype=np.int64)
         print(f'block {blk} natoms {target}')
+        print('  catbuild_bwd phases (stage, rebuild, tile-stage, tile-compute, tile-reduce, rest) us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((32, 33), (33, 34), (34, 35), (35, 36), (36, 37), (37, 38))], 'total', (ts[38] - ts[32]) / 100.0)
         print('  bwd 5->11->12->6 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((5, 11), (11, 12), (12, 6))])
         print('  bwd 2->13->28->3 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((2, 13), (13, 28), (28, 3))])
         print('  bwd 9->14->15->10 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((9, 14), (14, 15), (15, 10))])
