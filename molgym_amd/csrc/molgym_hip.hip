@@ -159,7 +159,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   const float soft_rad = fmaxf(1e-3f, fminf(c->max_distance, 2.1f)), soft_width = 0.2f;
   if (TE > 0) {
     GeomOut go = {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}};
-    hipLaunchKernelGGL(k_geom, dim3((TE + 127) / 128), dim3(128), 0, s, TE, N, pos, w.L, theta, (int)P.rad_scales[0],
+    hipLaunchKernelGGL(k_geom, dim3((4 * TE + 255) / 256), dim3(256), 0, s, TE, N, pos, w.L, theta, (int)P.rad_scales[0],
                        (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]), soft_rad, soft_width, go);
     LAUNCH_CHECK();
   }
