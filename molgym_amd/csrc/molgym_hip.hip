@@ -147,7 +147,15 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   hipStream_t s = (hipStream_t)stream;
   const int B = c->B, N = c->N, Z = c->Z, TA = c->TA, TE = c->TE, W = c->W;
 #define RC(x) do { rc = (x); if (rc) return rc; } while (0)
-  RC(prep_weights(s, theta, w));
+  // the derived weight matrices (and the zero of the expanded weight-gradient scratch the backward accumulates
+  // into) do not depend on the batch: side stream, beside the list / geometry kernels
+  hipEvent_t weights_ready = nullptr;
+  {
+    hipStream_t ss = side_fork(s);
+    RC(prep_weights(ss, theta, w));
+    HIP_CHECK(hipMemsetAsync(w.dwexp_all, 0, w.dwexp_floats * sizeof(float), ss));
+    if (ss != s) weights_ready = side_record();
+  }
   HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
   hipLaunchKernelGGL(k_prep_counts, dim3(1), dim3(256), 0, s, charges, B, N, TA, TE, w.L);
   LAUNCH_CHECK();
@@ -180,6 +188,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
                        c->bag_scale, charges, bags, w.L, w.scal);
     LAUNCH_CHECK();
     GemmG g = fwd_group(w.lin_in, theta, w.scal, 4 * Z, w.A0, 2 * CH, TA, 0, nullptr);
+    stream_wait(s, weights_ready);
+    weights_ready = nullptr;
     RC(launch_gemm(s, &g, 1));
   }
   for (int k = 0; k < 3 && TA > 0; ++k) {
@@ -237,6 +247,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     RC(launch_gemm(s, ga, 5));
   }
   // --- heads ---
+  stream_wait(s, weights_ready);  // only still pending for a batch of empty canvases
   const int Co = P.Co, nlat = P.nlat;
   APtrs A3;
   for (int l = 0; l < 5; ++l) A3.p[l] = w.A[3][l];
