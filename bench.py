@@ -30,6 +30,7 @@ def parse_args():
     p.add_argument('--batch', type=int, default=None, help='override the mini-batch size per GPU')
     p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
     return p.parse_args()
 
@@ -117,7 +118,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
-    if rank == 0:
+    if rank == 0 and not args.no_build:
         entry.build()
     if world > 1:
         dist.barrier()

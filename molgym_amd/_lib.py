@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmolgym_hip.so')
+LIB_PATH = os.environ.get('MOLGYM_HIP_LIB') or os.path.join(_HERE, 'libmolgym_hip.so')  # override: A/B builds
 MG_MAX_Z = 8
 
 

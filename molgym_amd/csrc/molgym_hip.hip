@@ -253,10 +253,6 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   for (int l = 0; l < 5; ++l) A3.p[l] = w.A[3][l];
   A3.C = Co;
   if (!smp && !use_staged_heads()) {  // action evaluation: all heads in one launch (heads_fused.inc)
-    if (TA > 0) {
-      hipLaunchKernelGGL(k_scalars, dim3((TA * Co + 255) / 256), dim3(256), 0, s, TA, Co, A3, w.inv);
-      LAUNCH_CHECK();
-    }
     HeadDims HD;
     HeadW HW;
     HeadBuf HB;
