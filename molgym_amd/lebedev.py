@@ -33,12 +33,33 @@ def _ylm_qm(xyz: np.ndarray) -> np.ndarray:
     return out
 
 
+def _antipodal_order(pts: np.ndarray, w: np.ndarray):
+    """Reorder the rule so that point g + NLEB/2 is exactly -point g (the rule is inversion symmetric).
+    Y_lm(-x) = (-1)^l Y_lm(x): the fused heads kernels read only the first half of the table and split the
+    coefficient sums by the parity of l; every other consumer sums over all points, where order is irrelevant."""
+    n = pts.shape[0]
+    key = {tuple(np.round(p, 12)): i for i, p in enumerate(pts)}
+    first, second, seen = [], [], set()
+    for i, p in enumerate(pts):
+        if i in seen:
+            continue
+        j = key[tuple(np.round(-p, 12) + 0.0)]
+        assert j != i and j not in seen and abs(w[i] - w[j]) <= 1e-15 * abs(w[i])
+        seen.update((i, j))
+        first.append(i)
+        second.append(j)
+    assert len(first) == n // 2
+    out = np.concatenate([pts[first], -pts[first]])  # exact negation, not the tabulated partner
+    return out, np.concatenate([w[first], w[first]])
+
+
 def lebedev_table() -> np.ndarray:
     """float32 [51][1730]: rows 2q / 2q+1 = Re / Im Y_q, row 50 = log weight."""
     from scipy.integrate import lebedev_rule
     pts, w = lebedev_rule(71)
     assert pts.shape == (3, NLEB)
-    y = _ylm_qm(np.ascontiguousarray(pts.T))
+    pts, w = _antipodal_order(np.ascontiguousarray(pts.T), w)
+    y = _ylm_qm(pts)
     tab = np.empty((51, NLEB), dtype=np.float64)
     tab[0:50:2] = y.real.T
     tab[1:50:2] = y.imag.T
