@@ -21,6 +21,9 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_blk), h_cgT_blk, sizeof(h_cgT_blk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_c), h_cgT_c, sizeof(h_cgT_c)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgT_key), h_cgT_key, sizeof(h_cgT_key)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_start), h_cgI_start, sizeof(h_cgI_start)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_pk), h_cgI_pk, sizeof(h_cgI_pk)));
+  HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_c), h_cgI_c, sizeof(h_cgI_c)));
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready = true;
   return MG_OK;
