@@ -119,6 +119,11 @@ typedef struct mg_int_cfg {
 int mg_int_num_params(const mg_int_cfg* cfg, int64_t* num_params);
 int mg_int_param_offsets(const mg_int_cfg* cfg, int64_t* offsets_out_host, int32_t* n_slots_host);
 int mg_int_workspace_bytes(const mg_int_cfg* cfg, size_t* bytes_host);
+/* Float offset / count of a named intermediate inside the workspace ("logitF" [TA], "logitE" [B][Z], "cout" [B][3]
+ * = phi_continuous output before tanh, "kv" [2][B] kappa logits, ...).  The rollout-side step(obs) of the Python
+ * agent reads the distribution parameters of each sub-action through it (internal/agent.py:206-292). */
+int mg_int_workspace_lookup(const mg_int_cfg* cfg, const char* name, int64_t* offset_floats_host,
+                            int64_t* count_floats_host);
 int mg_int_forward(const mg_int_cfg* cfg, const float* theta, const int32_t* mol_off, const int32_t* edge_off,
                    const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* ws,
                    size_t ws_bytes, float* out, void* stream);

@@ -45,6 +45,7 @@ SYMBOLS = {
     'mg_int_num_params': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_int64)]),
     'mg_int_param_offsets': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     'mg_int_workspace_bytes': (C.c_int, [C.POINTER(IntCfg), C.POINTER(C.c_size_t)]),
+    'mg_int_workspace_lookup': (C.c_int, [C.POINTER(IntCfg), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'mg_int_forward': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
     'mg_int_backward': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),

@@ -6,7 +6,8 @@ Drop-in for /root/reference/molgym/agents/internal/agent.py:17-353: same constru
 schnetpack SchNet embedding 3*B times per call at batch size 1 (agent.py:128,177); here the host builds ONE
 ragged batch of 3B molecules -- the canvases and the canvases plus the hypothetical new atom at +/- dihedral,
 placed by the z-matrix helper (internal/zmat.py:66-133, float64 numpy, no gradient, as in the reference which
-goes through ``to_numpy``) -- and the whole step is two C-ABI calls.
+goes through ``to_numpy``) -- and the whole step is two C-ABI calls.  ``step(observations)`` (rollouts) draws the
+sub-actions stage by stage from the same kernels (see ``_step_sample``).
 """
 import ctypes as C
 from typing import Any, Dict, List, Optional, Tuple
@@ -179,11 +180,109 @@ class SchNetAC(AbstractActorCritic):
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
         return IntBatch(cfg, t(mol_off), t(edge_off), t(molZ), t(molpos.astype(np.float32)), t(bags), t(acts))
 
+    def to_action_space(self, action: np.ndarray, observation: ObservationType):
+        """(atomic-number index, position) of the atom the 7-column action row places (agent.py:91-110)."""
+        stop, focus, element, distance, angle, dihedral, kappa = (float(x) for x in action)
+        if stop:
+            return None  # the reference builds an empty ase.Atoms here; this agent never stops (agent.py:190-191)
+        focus, element = int(round(focus)), int(round(element))
+        sign = -1.0 if int(round(kappa)) else 1.0
+        atoms, _ = self.observation_space.parse_positions(observation)
+        n = len(atoms)
+        pos = np.zeros((1, max(self.num_atoms, 1), 3))
+        for k, (_, xyz) in enumerate(atoms):
+            pos[0, k] = xyz
+        new = place_new_atoms(pos, np.array([n]), np.array([focus]), np.array([distance]), np.array([angle]),
+                              np.array([sign * dihedral]))[0]
+        index = self.action_space.zs.index(self.observation_space.zs[element])
+        return index, tuple(float(x) for x in new)
+
+    def _forward_nograd(self, batch: IntBatch):
+        lib = _lib.lib()
+        nbytes = C.c_size_t()
+        _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.theta.device)
+        out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
+        _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
+                                      _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
+                                      _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        self._last_ws = ws
+        return out, ws
+
+    def _ws_view(self, cfg, ws: torch.Tensor, name: str) -> torch.Tensor:
+        off, cnt = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().mg_int_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))
+        return ws.view(torch.float32)[off.value:off.value + cnt.value]
+
+    def _step_sample(self, observations: List[ObservationType]) -> Dict[str, Any]:
+        """step(obs) of the rollout (agent.py:181-353 with actions=None).  The sub-actions are conditioned on each
+        other (element on the focus, the continuous means on both, kappa on the placed atom), so the evaluation
+        kernels run once per stage on the partially filled action rows; every draw uses torch's device RNG
+        (Categorical / Normal as in the reference, so torch.manual_seed governs rollouts), argmax / means in
+        evaluation mode.  The last pass is the plain evaluation of the completed rows, so logp / ent / v are
+        exactly what step(obs, actions) returns for them."""
+        B, N, Z = len(observations), self.num_atoms, self.num_zs
+        dev = self.theta.device
+        _, _, bags, natoms = parse_observations_host(observations, self.zs, N)
+        acts = np.zeros((B, 7), dtype=np.float32)  # stop = 0: this agent does not stop
+        acts[:, 3] = 0.5 * (self.min_distance + self.max_distance)  # harmless placeholders for the early passes
+        acts[:, 4] = acts[:, 5] = 0.5 * np.pi
+        nat = torch.from_numpy(natoms.astype(np.int64)).to(dev)
+        with torch.no_grad():
+            # focus (agent.py:206-221): softmax over the real atoms; an empty canvas focuses slot 0
+            batch = self.make_batch(observations, acts)
+            _, ws = self._forward_nograd(batch)
+            logit_f = self._ws_view(batch.cfg, ws, 'logitF')[:batch.cfg.TA]
+            dense = torch.full((B, N), float('-inf'), device=dev)
+            slot = torch.arange(N, device=dev)[None, :] < nat[:, None]
+            dense[slot] = logit_f
+            dense[nat == 0, 0] = 0.0
+            p_f = torch.softmax(dense, dim=-1)
+            focus = torch.distributions.Categorical(probs=p_f).sample() if self.training else torch.argmax(p_f, -1)
+            acts[:, 1] = focus.cpu().numpy()
+            # element (agent.py:229-242): softmax over the elements left in the bag
+            batch = self.make_batch(observations, acts)
+            _, ws = self._forward_nograd(batch)
+            logit_e = self._ws_view(batch.cfg, ws, 'logitE')[:B * Z].view(B, Z)
+            mask_e = torch.from_numpy(bags > 0).to(dev)
+            dense = torch.where(mask_e, logit_e, torch.full_like(logit_e, float('-inf')))
+            dense[~mask_e.any(dim=-1), 0] = 0.0  # an exhausted bag never reaches the agent; keep the draw defined
+            p_e = torch.softmax(dense, dim=-1)
+            element = torch.distributions.Categorical(probs=p_e).sample() if self.training else torch.argmax(p_e, -1)
+            acts[:, 2] = element.cpu().numpy()
+            # distance / angle / dihedral (agent.py:246-292): Normal around tanh(mean) * width / 2 + center
+            batch = self.make_batch(observations, acts)
+            _, ws = self._forward_nograd(batch)
+            cout = self._ws_view(batch.cfg, ws, 'cout')[:B * 3].view(B, 3)
+            half_w = torch.tensor([0.5 * (self.max_distance - self.min_distance), 0.5 * np.pi, 0.5 * np.pi], device=dev)
+            center = torch.tensor([0.5 * (self.max_distance + self.min_distance), 0.5 * np.pi, 0.5 * np.pi], device=dev)
+            mean = torch.tanh(cout) * half_w + center
+            if self.training:
+                o, shp = self.slot_table['log_stds']
+                scale = torch.exp(1e-6 + self.theta[o:o + 3])
+                cont = torch.distributions.Normal(loc=mean, scale=scale).sample()
+                cont[:, 0].clamp_(min=0.001)  # the sampled distance must stay positive (agent.py:254-255)
+            else:
+                cont = mean
+            acts[:, 3:6] = cont.cpu().numpy()
+            # kappa (agent.py:294-315): keep / flip the dihedral, logits from the two hypothetical placements
+            batch = self.make_batch(observations, acts)
+            _, ws = self._forward_nograd(batch)
+            kv = self._ws_view(batch.cfg, ws, 'kv')[:2 * B].view(2, B).t()
+            kappa = torch.distributions.Categorical(logits=kv).sample() if self.training else torch.argmax(kv, -1)
+            acts[:, 6] = kappa.cpu().numpy()
+            batch = self.make_batch(observations, acts)
+            out, _ = self._forward_nograd(batch)
+        return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2],
+                'actions': [self.to_action_space(a, o) for a, o in zip(acts, observations)]}
+
     def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
         if self.theta.device.type != 'cuda':
             raise RuntimeError('SchNetAC runs on the HIP device only (no CPU fallback)')
         if actions is None:
-            raise NotImplementedError('rollout-side sampling of the internal agent is not on the device yet')
+            return self._step_sample(observations)
         batch = self.make_batch(observations, actions)
         out = _IntStep.apply(self.theta, self, batch)
-        return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2]}
+        acts = np.asarray(actions, dtype=np.float32)
+        return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2],
+                'actions': [self.to_action_space(a, o) for a, o in zip(acts, observations)]}

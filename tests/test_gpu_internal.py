@@ -83,3 +83,65 @@ def test_small_canvases_and_masks(built_lib):
         exp = ref.step(obs, data['act'], dtype=torch.float64)
     for k in ('logp', 'ent', 'v'):
         assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
+def test_rollout_sampling_is_consistent_with_evaluation(built_lib):
+    """step(obs) draws a full 7-column action row per sample; evaluating the drawn rows with step(obs, actions)
+    and with the float64 oracle reproduces the logp / ent / v the sampling call reported."""
+    ac, ref = _pair(5, width=64)
+    data = make_batch_internal(24, N, ZS, seed=11)
+    obs = list(data['obs'])
+    canvas, bag = obs[1]
+    obs[0] = (tuple((0, (0.0, 0.0, 0.0)) for _ in canvas), bag)  # an empty canvas: focus must be slot 0
+    for training in (True, False):
+        ac.training = training
+        torch.manual_seed(123)
+        out = ac.step(obs)
+        a = out['a'].cpu().numpy()
+        assert a.shape == (len(obs), 7) and np.all(a[:, 0] == 0)
+        natoms = np.array([sum(1 for it in o[0] if ZS[it[0]] != 0) for o in obs])
+        assert np.all(a[:, 1] < np.maximum(natoms, 1)) and a[0, 1] == 0
+        for b, (_, bg) in enumerate(obs):
+            assert bg[int(a[b, 2])] > 0  # only elements left in the bag are drawn
+        assert np.all(a[:, 3] >= 0.001) and set(np.unique(a[:, 6])) <= {0.0, 1.0}
+        with torch.no_grad():
+            again = ac.step(obs, a)
+            exp = ref.step(obs, a, dtype=torch.float64)
+        for k in ('logp', 'ent', 'v'):
+            assert torch.equal(out[k], again[k]), k
+            assert rel_err(out[k], exp[k]) < 1e-5, k
+        assert len(out['actions']) == len(obs)
+        idx, pos = out['actions'][1]
+        assert 0 <= idx < len(ZS) and len(pos) == 3
+        # the returned position is the z-matrix placement of the drawn row (kappa = 1 flips the dihedral)
+        atoms = [np.asarray(x, dtype=np.float64) for l, x in obs[1][0] if ZS[l] != 0]
+        sign = -1.0 if a[1, 6] else 1.0
+        want = position_atom(atoms, int(a[1, 1]), float(a[1, 3]), float(a[1, 4]), sign * float(a[1, 5]))
+        assert np.allclose(pos, want, atol=1e-9)
+    # evaluation mode is deterministic; training mode follows torch's RNG
+    ac.training = True
+    torch.manual_seed(7)
+    a1 = ac.step(obs)['a'].cpu().numpy()
+    torch.manual_seed(7)
+    a2 = ac.step(obs)['a'].cpu().numpy()
+    torch.manual_seed(8)
+    a3 = ac.step(obs)['a'].cpu().numpy()
+    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
+
+
+def test_sampled_focus_frequencies_follow_the_softmax(built_lib):
+    """many draws for one canvas: empirical focus / kappa frequencies match the distribution parameters read back"""
+    ac, _ = _pair(9, width=64)
+    data = make_batch_internal(8, N, ZS, seed=3)
+    full = max(data['obs'], key=lambda o: sum(1 for it in o[0] if ZS[it[0]] != 0))
+    obs = [full] * 512
+    ac.training = True
+    torch.manual_seed(0)
+    out = ac.step(obs)
+    a = out['a'].cpu().numpy()
+    n = sum(1 for it in full[0] if ZS[it[0]] != 0)
+    batch = ac.make_batch(obs[:1], a[:1])
+    _, ws = ac._forward_nograd(batch)
+    p = torch.softmax(ac._ws_view(batch.cfg, ws, 'logitF')[:n], 0).cpu().numpy()
+    freq = np.bincount(a[:, 1].astype(int), minlength=n)[:n] / len(obs)
+    assert np.abs(freq - p).max() < 4.0 * np.sqrt(0.25 / len(obs))
