@@ -145,3 +145,41 @@ def test_sampled_focus_frequencies_follow_the_softmax(built_lib):
     p = torch.softmax(ac._ws_view(batch.cfg, ws, 'logitF')[:n], 0).cpu().numpy()
     freq = np.bincount(a[:, 1].astype(int), minlength=n)[:n] / len(obs)
     assert np.abs(freq - p).max() < 4.0 * np.sqrt(0.25 / len(obs))
+
+
+def test_ppo_train_with_sampled_rollout_tracks_the_oracle_loop(built_lib):
+    """rollout rows drawn by SchNetAC.step(obs), then two epochs of molgym_amd.ppo.train (generic autograd path)
+    against the same loop on the float64 oracle with torch Adam"""
+    from molgym_amd import ppo
+    from oracle.ppo_ref import batch_indices_ref, compute_loss_ref
+    ac, ref = _pair(12, width=64)
+    data = make_batch_internal(24, N, ZS, seed=21)
+    ac.training = True
+    torch.manual_seed(1)
+    drawn = ac.step(list(data['obs']))
+    data['act'] = drawn['a'].cpu().numpy().astype(np.float64)
+    data['logp'] = drawn['logp'].detach().double().cpu().numpy() - 0.002
+    opt = torch.optim.Adam(ac.parameters(), lr=3e-4)
+    ropt = torch.optim.Adam(ref.parameters(), lr=3e-4)
+    np.random.seed(5)
+    infos = ppo.train(ac, opt, data, mini_batch_size=10, clip_ratio=0.2, target_kl=1e9, vf_coef=0.5, entropy_coef=0.01,
+                      gradient_clip=0.5, max_num_steps=2)
+    np.random.seed(5)
+    for _ in range(2):
+        ropt.zero_grad()
+        stats = []
+        for idx in batch_indices_ref(24, 10):
+            sub = ppo.collect_data_batch(data, idx)
+            loss, info = compute_loss_ref(ref, sub, 0.2, 0.5, 0.01, step_dtype=torch.float64)
+            loss.backward()
+            stats.append(info)
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        ropt.step()
+    assert infos['num_opt_steps'] == 2
+    mean = ppo.compute_mean_dict(stats)
+    for k in ppo.KEYS:
+        assert abs(infos[k] - mean[k]) < 2e-4 * max(1.0, abs(mean[k])), (k, infos[k], mean[k])
+    new = ac.export_state_dict()
+    for k, v in ref.state_dict().items():
+        d = (new[k].double().cpu() - v).abs().max().item()
+        assert d < 1e-4, (k, d)
