@@ -160,10 +160,15 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     if (ss != s) weights_ready = side_record();
   }
   HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
-  hipLaunchKernelGGL(k_prep_counts, dim3(1), dim3(256), 0, s, charges, B, N, TA, TE, w.L);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fill_lists, dim3(B), dim3(64), 0, s, B, w.L);
-  LAUNCH_CHECK();
+  if (B <= 1024 && N <= 16) {
+    hipLaunchKernelGGL(k_lists_small, dim3(1), dim3(1024), 0, s, charges, B, N, TA, TE, w.L);
+    LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(k_prep_counts, dim3(1), dim3(256), 0, s, charges, B, N, TA, TE, w.L);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fill_lists, dim3(B), dim3(64), 0, s, B, w.L);
+    LAUNCH_CHECK();
+  }
   int maxz = 0;
   ZsArr zs;
   for (int i = 0; i < 8; ++i) { zs.z[i] = i < Z ? c->zs[i] : -1; if (i < Z && c->zs[i] > maxz) maxz = c->zs[i]; }
