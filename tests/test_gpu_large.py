@@ -1,0 +1,114 @@
+"""Parity at BASELINE's full sizes, where the float64 oracle is out of reach: size-independent properties of the
+path (SO(3) invariance, independence of the samples of a mini-batch, additivity of the gradient over shards) and
+agreement of the kernel families that only large shapes select (MFMA forms vs the lane-per-row VALU forms, the
+16-byte dW form, the LDS-staged row GEMM, the two-kernel list build) on the same inputs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from molgym_amd.agents.covariant import CovariantAC
+from molgym_amd.spaces import ActionSpace, ObservationSpace
+from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _agent(cfg, seed=0):
+    torch.manual_seed(seed)
+    return CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']),
+                       bag_scale=cfg['bag_scale'], beta=cfg['beta'], device=torch.device('cuda:0'), **MODEL_DEFAULTS)
+
+
+def _rotation(seed):
+    q, r = np.linalg.qr(np.random.default_rng(seed).normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def _rotate(data, R):
+    obs = []
+    for canvas, bag in data['obs']:
+        obs.append((tuple((label, tuple(R @ np.asarray(xyz, dtype=np.float64))) for label, xyz in canvas), bag))
+    act = np.array(data['act'], dtype=np.float64)
+    act[:, 3:6] = act[:, 3:6] @ R.T
+    return obs, act
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg5'])
+def test_rotation_invariance_at_full_size(built_lib, name):
+    """a global rotation of canvas and orientation leaves logp, entropy and value unchanged (test_agent.py:43-123
+    checks the same property of the reference at toy size)"""
+    cfg = CONFIGS[name]
+    ac = _agent(cfg)
+    data = make_batch(cfg['batch'], cfg['canvas_size'], cfg['zs'], seed=5)
+    with torch.no_grad():
+        a = ac.forward_batch(ac.prepare_batch(data['obs'], data['act'])).clone()
+        obs_r, act_r = _rotate(data, _rotation(1))
+        b = ac.forward_batch(ac.prepare_batch(obs_r, act_r)).clone()
+    assert torch.isfinite(a).all()
+    scale = a.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+    assert ((a - b).abs() / scale).max().item() < 2e-4  # f32 evaluation of a 3-level CG network at N = 12 / 40
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg5'])
+def test_samples_are_independent_at_full_size(built_lib, name):
+    """the outputs of a sample do not depend on the rest of the mini-batch (ragged compaction, tiling, atomics)"""
+    cfg = CONFIGS[name]
+    ac = _agent(cfg)
+    data = make_batch(cfg['batch'], cfg['canvas_size'], cfg['zs'], seed=6)
+    with torch.no_grad():
+        full = ac.forward_batch(ac.prepare_batch(data['obs'], data['act'])).clone()
+        lo, hi = cfg['batch'] // 3, cfg['batch'] // 3 + 37
+        part = ac.forward_batch(ac.prepare_batch(data['obs'][lo:hi], data['act'][lo:hi])).clone()
+    # forward sums run in a fixed order per sample, so the only difference is the tiling of the MFMA row blocks
+    assert (full[:, lo:hi] - part).abs().max().item() < 1e-5 * max(1.0, full.abs().max().item())
+
+
+def test_gradient_is_additive_over_shards_at_full_size(built_lib):
+    """data-parallel contract on cfg3: the gradient of a mini-batch is the sum of its shards'
+    gradients with loss scale B_shard / B"""
+    cfg = CONFIGS['cfg3']
+    ac = _agent(cfg)
+    B = cfg['batch']
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=7)
+    cut = B // 2 + 17
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    ac.ppo_minibatch(ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret']), 0.2, 0.5, 0.01)
+    torch.cuda.synchronize()
+    whole = ac.theta.grad.clone()
+    ac.theta.grad.zero_()
+    for sl in (slice(0, cut), slice(cut, B)):
+        n = len(data['obs'][sl])
+        ac.ppo_minibatch(ac.prepare_batch(data['obs'][sl], data['act'][sl], data['logp'][sl], data['adv'][sl],
+                                          data['ret'][sl]), 0.2, 0.5, 0.01, loss_scale=n / B)
+    torch.cuda.synchronize()
+    assert torch.isfinite(whole).all()
+    assert (ac.theta.grad - whole).abs().max().item() < 2e-4 * whole.abs().max().item()
+
+
+def _run_worker(name, env_extra, path):
+    env = dict(os.environ)
+    env.update(env_extra)
+    subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'large_worker.py'), name, path], check=True, cwd=ROOT,
+                   env=env, timeout=600)
+    return np.load(path)
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+def test_kernel_families_agree_at_full_size(built_lib, tmp_path, name):
+    """MFMA GEMM forms + side stream (default) against the VALU forms on one stream, same inputs and weights: the
+    predictions, the loss statistics and the whole gradient vector"""
+    a = _run_worker(name, {}, str(tmp_path / 'a.npz'))
+    b = _run_worker(name, {'MG_MFMA': '0', 'MG_MFMA_DX': '0', 'MG_MFMA_DW': '0', 'MG_NO_SIDE_STREAM': '1'},
+                    str(tmp_path / 'b.npz'))
+    assert np.isfinite(a['grad']).all() and np.isfinite(a['pred']).all()
+    assert np.abs(a['pred'] - b['pred']).max() < 1e-5 * max(1.0, np.abs(b['pred']).max())
+    assert np.abs(a['stats'] - b['stats']).max() < 1e-5 * max(1.0, np.abs(b['stats']).max())
+    assert np.abs(a['grad'] - b['grad']).max() < 2e-4 * np.abs(b['grad']).max()
