@@ -64,6 +64,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                                '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        # torch first: its bundled HIP runtime must be the one this library binds to (loading the library before torch
+        # leaves two runtimes in the process and the second one sees no device)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
