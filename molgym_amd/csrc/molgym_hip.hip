@@ -149,6 +149,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int B = c->B, N = c->N, Z = c->Z, TA = c->TA, TE = c->TE, W = c->W;
+  side_policy(TE >= MG_SIDE_MIN_EDGES);
 #define RC(x) do { rc = (x); if (rc) return rc; } while (0)
   // the derived weight matrices (and the zero of the expanded weight-gradient scratch the backward accumulates
   // into) do not depend on the batch: side stream, beside the list / geometry kernels
