@@ -184,13 +184,12 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     // the radial Linears of all three levels depend on the geometry only: side stream, beside the input Linear
     // and the first DotMatrix (they fill the radial columns of cat_e[k]; joined before the first edge cat-mix)
     hipStream_t ss = side_fork(s);
-    for (int k = 0; k < 3; ++k) {
-      GemmG gr[5];
+    GemmG gr[15];  // one launch for the 3 x 5 radial Linears
+    for (int k = 0; k < 3; ++k)
       for (int l = 0; l < 5; ++l)
-        gr[l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE, 0,
-                          nullptr);
-      RC(launch_gemm(ss, gr, 5));
-    }
+        gr[5 * k + l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE,
+                                  0, nullptr);
+    RC(launch_gemm(ss, gr, 15));
   }
   if (TA > 0) {
     hipLaunchKernelGGL(k_atom_scalars, dim3((TA * 4 * Z + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
@@ -224,12 +223,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
     }
     if (k == 0) side_join(s);  // radial columns of every level are in place
-    if (k == 0) {  // l = 0 has a different reduction width (and tile alignment) than l >= 1
-      RC(launch_gemm(s, ge, 1));
-      RC(launch_gemm(s, ge + 1, 4));
-    } else {
-      RC(launch_gemm(s, ge, 5));
-    }
+    RC(launch_gemm(s, ge, 5));  // (level 0: l = 0 has a different reduction width; the MFMA row form takes both)
     // --- atom level k (CG aggregate, CG power, cat-mix) ---
     EPtrs E;
     for (int l = 0; l < 5; ++l) {
