@@ -108,7 +108,7 @@ static int check_common(const mg_cov_cfg* c, const PLayout& P, const WS& w, size
   return MG_OK;
 }
 
-static int prep_weights(hipStream_t s, const float* theta, WS& w) {
+static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scratch = false) {
   std::vector<Lin*> all;
   for (int k = 0; k < 3; ++k)
     for (int l = 0; l < 5; ++l) { all.push_back(&w.rad[k][l]); all.push_back(&w.edge[k][l]); all.push_back(&w.atom[k][l]); }
@@ -123,6 +123,7 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w) {
       Lin* L = all[i0 + i];
       a.w[i] = {theta + L->w_off, L->mf, L->mb, L->O, L->Q, L->ldf, L->ldb, L->cplx};
     }
+    if (zero_scratch && i0 == 0) { a.zero_f = w.dwexp_all; a.zero_n = w.dwexp_floats; a.zero_i4 = w.L.err; }
     hipLaunchKernelGGL(k_prep_weights, dim3(8, n), dim3(256), 0, s, a);
     LAUNCH_CHECK();
   }
@@ -156,11 +157,15 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   hipEvent_t weights_ready = nullptr;
   {
     hipStream_t ss = side_fork(s);
-    RC(prep_weights(ss, theta, w));
-    HIP_CHECK(hipMemsetAsync(w.dwexp_all, 0, w.dwexp_floats * sizeof(float), ss));
-    if (ss != s) weights_ready = side_record();
+    if (ss == s) {
+      RC(prep_weights(s, theta, w, true));  // one launch: derived weights, zero of dwexp and of the error flags
+    } else {
+      RC(prep_weights(ss, theta, w));
+      HIP_CHECK(hipMemsetAsync(w.dwexp_all, 0, w.dwexp_floats * sizeof(float), ss));
+      weights_ready = side_record();
+      HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
+    }
   }
-  HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
   if (B <= 1024 && N <= 16) {
     hipLaunchKernelGGL(k_lists_small, dim3(1), dim3(1024), 0, s, charges, B, N, TA, TE, w.L);
     LAUNCH_CHECK();
@@ -192,13 +197,12 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     RC(launch_gemm(ss, gr, 15));
   }
   if (TA > 0) {
-    hipLaunchKernelGGL(k_atom_scalars, dim3((TA * 4 * Z + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
-                       c->bag_scale, charges, bags, w.L, w.scal);
-    LAUNCH_CHECK();
-    GemmG g = fwd_group(w.lin_in, theta, w.scal, 4 * Z, w.A0, 2 * CH, TA, 0, nullptr);
     stream_wait(s, weights_ready);
     weights_ready = nullptr;
-    RC(launch_gemm(s, &g, 1));
+    hipLaunchKernelGGL(k_input_linear, dim3((TA * 2 * CH + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
+                       c->bag_scale, charges, bags, w.L, w.lin_in.mf, w.lin_in.ldf,
+                       w.lin_in.b_off >= 0 ? theta + w.lin_in.b_off : nullptr, 2 * CH, w.scal, w.A0);
+    LAUNCH_CHECK();
   }
   for (int k = 0; k < 3 && TA > 0; ++k) {
     // --- edge level k (cormorant EdgeLevel: DotMatrix, cat-mix, soft mask) ---
