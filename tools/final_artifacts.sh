@@ -15,5 +15,5 @@ BENCH_WATCHDOG=250 timeout -k 5 300 python bench.py --steps 30 --warmup 5 > $out
 tail -1 $out/bench.json | cut -c1-1500
 timeout -k 5 150 rocprofv3 --kernel-trace -d $out -o prof -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/bench_prof.log 2>&1
 python tools/rocpd_summary.py $out/prof_results.db $out/kernel_stats.csv 43 > /dev/null && head -16 $out/kernel_stats.csv && tail -1 $out/kernel_stats.csv
-python tools/rocpd_timeline.py $out/prof_results.db > $out/timeline.txt 2>&1
+python tools/rocpd_timeline.py $out/prof_results.db k_prep_weights > $out/timeline.txt 2>&1
 rm -f $out/fetch_results.db $out/write_results.db $out/prof_results.db
