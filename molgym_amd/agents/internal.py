@@ -209,6 +209,25 @@ class SchNetAC(AbstractActorCritic):
         self._last_ws = ws
         return out, ws
 
+    def ppo_minibatch(self, batch: IntBatch, logp, adv, ret, clip_ratio: float, vf_coef: float,
+                      entropy_coef: float) -> torch.Tensor:
+        """forward + float64 PPO loss + hand-written backward on the device (ppo.py:124-131), gradients accumulated
+        into theta.grad; `logp / adv / ret` are float64 device tensors.  Returns the 6 loss statistics."""
+        lib = _lib.lib()
+        out, ws = self._forward_nograd(batch)
+        B = batch.cfg.B
+        dev = self.theta.device
+        stats = torch.empty(6, dtype=torch.float64, device=dev)
+        gout = torch.empty(3, B, dtype=torch.float32, device=dev)
+        _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(logp), _ptr(adv), _ptr(ret), clip_ratio, vf_coef, entropy_coef,
+                                   _ptr(stats), _ptr(gout), _stream()))
+        if self.theta.grad is None:
+            self.theta.grad = torch.zeros_like(self.theta)
+        _lib.check(lib.mg_int_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
+                                       _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
+                                       _ptr(ws), ws.numel(), _ptr(gout), _ptr(self.theta.grad), _stream()))
+        return stats
+
     def _ws_view(self, cfg, ws: torch.Tensor, name: str) -> torch.Tensor:
         off, cnt = C.c_int64(), C.c_int64()
         _lib.check(_lib.lib().mg_int_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))

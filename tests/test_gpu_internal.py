@@ -183,3 +183,23 @@ def test_ppo_train_with_sampled_rollout_tracks_the_oracle_loop(built_lib):
     for k, v in ref.state_dict().items():
         d = (new[k].double().cpu() - v).abs().max().item()
         assert d < 1e-4, (k, d)
+
+
+def test_device_minibatch_equals_autograd_path(built_lib):
+    """SchNetAC.ppo_minibatch (forward + float64 loss kernel + backward, no autograd graph) against
+    molgym_amd.ppo.compute_loss + loss.backward() through the autograd Function"""
+    from molgym_amd import ppo
+    ac, _ = _pair(14, width=64)
+    data = make_batch_internal(20, N, ZS, seed=31)
+    loss, info = ppo.compute_loss(ac, data, clip_ratio=0.2, vf_coef=0.5, entropy_coef=0.01)
+    ac.theta.grad = None
+    loss.backward()
+    want = ac.theta.grad.clone()
+    ac.theta.grad = None
+    dev = ac.theta.device
+    f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+    stats = ac.ppo_minibatch(ac.make_batch(data['obs'], data['act']), f64(data['logp']), f64(data['adv']),
+                             f64(data['ret']), 0.2, 0.5, 0.01)
+    torch.cuda.synchronize()
+    assert (ac.theta.grad - want).abs().max().item() < 1e-5 * want.abs().max().item()
+    assert abs(stats[0].item() - info['policy_loss']) < 1e-6 * max(1.0, abs(info['policy_loss']))
