@@ -28,6 +28,8 @@ def parse_args():
     p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--config', default='cfg2', help='synthetic workload (molgym_amd/synthetic.py)')
     p.add_argument('--batch', type=int, default=None, help='override the mini-batch size per GPU')
+    p.add_argument('--agent', default='covariant', choices=['covariant', 'internal'],
+                   help="'internal' = SchNetAC (BASELINE configs[0]); single GPU, no roofline object")
     p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
@@ -98,8 +100,93 @@ def cpu_baseline(cfg_name, B, seed, state_dict, budget_s):
                       f'reference op granularity'}
 
 
+def _cpu_baseline_worker_internal(B, seed, budget_s, threads, sd_path):
+    """SchNetAC leg of the CPU baseline (child process)."""
+    import torch
+    from molgym_amd.synthetic import make_batch_internal
+    from oracle.internal_ref import SchNetACRef
+    from oracle.ppo_ref import compute_loss_ref
+    torch.set_num_threads(threads)
+    ref = SchNetACRef([0, 9, 16], 7, (0.8, 1.8), 128)
+    ref.load_state_dict(torch.load(sd_path), strict=True)
+    data = make_batch_internal(B, 7, [0, 9, 16], seed=seed)
+    t0, n = time.perf_counter(), 0
+    while True:
+        ref.zero_grad()
+        loss, _ = compute_loss_ref(ref, data, 0.2, 0.5, 0.01)
+        loss.backward()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 10:
+            break
+    print(json.dumps({'dt': (time.perf_counter() - t0) / n, 'n': n}))
+
+
+def main_internal(args):
+    """`--agent internal`: SchNetAC forward + float64 loss + backward on BASELINE configs[0] (SF6, canvas 7,
+    mini-batch 140), the ragged 3B-molecule batch resident in HBM.  Extra measurement, not the driver's metric."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    if not args.no_build:
+        entry.build()
+    from molgym_amd.agents.internal import SchNetAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    from molgym_amd.synthetic import make_batch_internal
+    zs, N = [0, 9, 16], 7
+    B = args.batch or 140
+    torch.manual_seed(0)
+    ac = SchNetAC(ObservationSpace(N, zs), ActionSpace(zs), (0.8, 1.8), 128, device='cuda:0')
+    data = make_batch_internal(B, N, zs, seed=0)
+    batch = ac.make_batch(data['obs'], data['act'])
+    f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(ac.theta.device)
+    logp, adv, ret = f64(data['logp']), f64(data['adv']), f64(data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+
+    def step():
+        ac.theta.grad.zero_()
+        return ac.ppo_minibatch(batch, logp, adv, ret, 0.2, 0.5, 0.01)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if not torch.isfinite(stats).all():
+        raise SystemExit('non-finite loss statistics')
+    line = {'metric': 'PPO mini-batch fwd+bwd samples/sec (internal, canvas_size=7)', 'value': B * args.steps / elapsed,
+            'unit': 'samples/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[0]: SchNet internal-coordinate actor-critic, zs={zs}, canvas_size={N}, '
+                                   f'mini_batch={B}, 3B-molecule ragged batch resident in HBM'},
+            'roofline': None, 'cpu_baseline': None}
+    if not args.no_cpu_baseline:
+        with tempfile.TemporaryDirectory() as tmp:
+            sd_path = os.path.join(tmp, 'sd.pt')
+            torch.save({k: v.float().cpu() for k, v in ac.export_state_dict().items()}, sd_path)
+            code = ('import sys; sys.path.insert(0, %r); import bench; '
+                    'bench._cpu_baseline_worker_internal(%d, 0, %f, 8, %r)' % (ROOT, B, args.cpu_seconds, sd_path))
+            try:
+                res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                                     timeout=4 * args.cpu_seconds + 120)
+                rec = json.loads(res.stdout.strip().splitlines()[-1])
+                line['cpu_baseline'] = {'value': B / rec['dt'], 'unit': 'samples/s', 'cores': 8, 'kind': 'port',
+                                        'sample': f"{rec['n']} fwd+bwd passes over the same {B}-sample mini-batch, "
+                                                  f'float32, 8 threads, oracle/ restatement'}
+            except Exception:
+                pass
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
+    if args.agent == 'internal':
+        return main_internal(args)
     wd = float(os.environ.get('BENCH_WATCHDOG', '0'))
     if wd > 0:  # dump all Python stacks and exit if the run wedges
         import faulthandler
