@@ -166,7 +166,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
     }
   }
-  if (B <= 1024 && N <= 16) {
+  if (B <= MG_LISTS_SMALL_B && N <= 16) {
     hipLaunchKernelGGL(k_lists_small, dim3(1), dim3(1024), 0, s, charges, B, N, TA, TE, w.L);
     LAUNCH_CHECK();
   } else {
