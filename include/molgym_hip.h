@@ -99,6 +99,23 @@ int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
                     const float* gout, float* grad_theta, void* stream);
 
+/* ---- head outputs of the forward that just ran (what step()'s `dists` are built from, agent.py:224-286,325-331) ----
+ * Packs, sample-major, out of the workspace:  focus logits [B][N] (0 beyond the sample's atoms) | natoms [B] (as f32) |
+ * element logits [B][Z] | GMM head [B][2G] (mixture logits, then pre-tanh means) | conditioned orientation
+ * coefficients [B][25][CE = 4][2] (q = l*l+l+m) | log Z [B].   out holds B * (N + 1 + Z + 2G + 200 + 1) floats.   */
+int mg_cov_head_outputs(const mg_cov_cfg* cfg, const void* ws, size_t ws_bytes, float* out, void* stream);
+
+/* ---- orientation density on caller-supplied points ------------------------------------------------------
+ * What dists[-1] of CovariantAC.step()'s return (covariant/agent.py:325-331) evaluates in .log_prob(value) /
+ * .prob(value): ExpSO3Distribution (spherical_dists.py:273-286) when has_beta, SO3Distribution (:160-179) otherwise.
+ *   coef   [B][25][2] f32 channel-summed coefficients AFTER normalize_alms (so3_tools.py:68-75), q = l*l+l+m
+ *   points [S][Bp][3] f32, Bp == B, or 1 to broadcast one grid over the samples; normalised to unit length
+ *          inside (cormorant SphericalHarmonics(normalize=True)), a zero vector keeps Y_00 only
+ *   logz   [B] f32 (has_beta), empty [B] u8 or NULL (SO3Distribution's uniform density on an empty canvas)
+ *   mode   0 = log_prob, 1 = prob, 2 = unnormalised log_prob (has_beta only);  out [S][B] f32               */
+int mg_so3_density(int32_t B, int64_t S, int32_t Bp, const float* coef, const float* points, int32_t has_beta,
+                   float beta, const float* logz, const uint8_t* empty, int32_t mode, float* out, void* stream);
+
 /* ---- internal-coordinate agent: SchNetAC.step(obs, actions), molgym/agents/internal/agent.py:181-353 ----
  * The schnetpack SchNet embedding is evaluated once over 3B molecules: set 0 = the canvases (n_b atoms), sets 1
  * and 2 = canvas + the new atom placed by zmat.position_atom_helper (internal/zmat.py:96-133, done on the host

@@ -7,6 +7,7 @@ training path, ppo.py:26 -- runs in libmolgym_hip.so through one autograd node;
 there is no eager / CPU fallback.
 """
 import ctypes as C
+from collections import OrderedDict
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -16,14 +17,22 @@ from .. import _lib, layout
 from ..lebedev import lebedev_table
 from ..spaces import ActionSpace, ObservationSpace, ObservationType
 from .base import AbstractActorCritic
+from .dists import StepDists
+
+try:
+    from torch.nn.modules.module import _IncompatibleKeys
+except ImportError:  # very old / very new torch: same two fields
+    from collections import namedtuple
+    _IncompatibleKeys = namedtuple('IncompatibleKeys', ['missing_keys', 'unexpected_keys'])
 
 
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current stream ON THE AGENT'S DEVICE (not on whatever device happens to be current)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def parse_observations_host(observations: List[ObservationType], zs: List[int], canvas_size: int):
@@ -82,8 +91,10 @@ class _CovStep(torch.autograd.Function):
         _lib.check(lib.mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=theta.device)
         out = torch.empty(3, cfg.B, dtype=torch.float32, device=theta.device)
-        _lib.check(lib.mg_cov_forward(C.byref(cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags), _ptr(actions),
-                                      _ptr(ac.leb), _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        with torch.cuda.device(theta.device):
+            _lib.check(lib.mg_cov_forward(C.byref(cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
+                                          _ptr(actions), _ptr(ac.leb), _ptr(ws), nbytes.value, _ptr(out),
+                                          _stream(theta.device)))
         ctx.save_for_backward(theta, pos, charges, bags, actions, ws)
         ctx.cfg, ctx.ac = cfg, ac
         ac._last_ws = ws
@@ -95,9 +106,10 @@ class _CovStep(torch.autograd.Function):
         lib = _lib.lib()
         grad = torch.zeros_like(theta)
         gout = gout.contiguous()
-        _lib.check(lib.mg_cov_backward(C.byref(ctx.cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
-                                       _ptr(actions), _ptr(ctx.ac.leb), _ptr(ws), ws.numel(), _ptr(gout), _ptr(grad),
-                                       _stream()))
+        with torch.cuda.device(theta.device):
+            _lib.check(lib.mg_cov_backward(C.byref(ctx.cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
+                                           _ptr(actions), _ptr(ctx.ac.leb), _ptr(ws), ws.numel(), _ptr(gout),
+                                           _ptr(grad), _stream(theta.device)))
         return grad, None, None, None, None, None, None
 
 
@@ -191,6 +203,39 @@ class CovariantAC(AbstractActorCritic):
             for k, (o, s) in self.slot_table.items():
                 self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
 
+    # state_dict() / load_state_dict() speak the REFERENCE module's keys (one entry per tensor the reference's
+    # CovariantAC registers, agent.py:58-143; names in layout.py), so a checkpoint written through state_dict() by
+    # either implementation loads into the other.  The flat vector itself is also accepted ({'theta': ...}).
+    _IGNORED_SUFFIXES = ('soft_cut_rad', 'soft_cut_width', 'zero', 'channel_offsets', 'zs_tensor', 'leb')
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        t = self.theta if keep_vars else self.theta.detach()
+        for k, (o, s) in self.slot_table.items():
+            out[prefix + k] = t[o:o + int(np.prod(s))].view(s)
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = dict(state_dict)
+        if set(sd) == {'theta'}:
+            with torch.no_grad():
+                self.theta.copy_(sd['theta'].to(self.theta).reshape(-1))
+            return _IncompatibleKeys([], [])
+        missing = [k for k in self.slot_table if k not in sd]
+        unexpected = [k for k in sd if k not in self.slot_table and not k.endswith(self._IGNORED_SUFFIXES)]
+        bad_shape = [k for k, (o, s) in self.slot_table.items() if k in sd and tuple(sd[k].shape) != tuple(s)]
+        if bad_shape:
+            raise RuntimeError('size mismatch for ' + ', '.join(
+                f'{k}: checkpoint {tuple(sd[k].shape)} vs model {self.slot_table[k][1]}' for k in bad_shape))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'Error(s) in loading state_dict for CovariantAC: missing keys {missing}, '
+                               f'unexpected keys {unexpected}')
+        with torch.no_grad():
+            for k, (o, s) in self.slot_table.items():
+                if k in sd:
+                    self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
+        return _IncompatibleKeys(missing, unexpected)
+
     # -- batch ----------------------------------------------------------------------------------
     def _make_cfg(self, B: int, natoms: np.ndarray) -> _lib.CovCfg:
         cfg = _lib.CovCfg()
@@ -205,15 +250,41 @@ class CovariantAC(AbstractActorCritic):
         cfg.min_distance, cfg.max_distance = float(self.min_distance), float(self.max_distance)
         return cfg
 
+    def _guard(self):
+        """every C call runs with the agent's device current: the library keeps per-device state (CG tables in
+        __constant__ memory, function attributes, side stream) keyed by hipGetDevice()."""
+        return torch.cuda.device(self.theta.device)
+
+    def _s(self):
+        return _stream(self.theta.device)
+
     def to_action_space(self, action: np.ndarray, observation: ObservationType):
+        """agent.py:147-163 without the ase round trip: position = focused atom + distance * direction, where the
+        focus indexes the non-null canvas items in canvas order (ObservationSpace.parse drops the null items,
+        spaces.py:55-61,106-107)."""
         assert action.shape == (6, )
         focus, element_index = int(round(float(action[0]))), int(round(float(action[1])))
-        atoms, _ = self.observation_space.parse_positions(observation)
+        atoms = [xyz for label, xyz in observation[0] if self.zs[label] != 0]
         if len(atoms):
-            position = tuple(np.asarray(atoms[focus][1]) + action[2] * action[3:6])
+            position = tuple(np.asarray(atoms[focus], dtype=np.float64) + action[2] * action[3:6])
         else:
             position = (0.0, 0.0, 0.0)
         return element_index, position
+
+    def _check_actions(self, actions, B: int) -> np.ndarray:
+        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
+        assert acts.shape == (B, 6)
+        N = self.observation_space.canvas_space.size
+        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
+        if B and (focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs)):
+            raise RuntimeError('index out of range in one-hot selection')  # to_one_hot's scatter_ error
+        return acts
+
+    def _dists(self, cfg, ws: torch.Tensor, bags: torch.Tensor) -> StepDists:
+        block = torch.empty(StepDists.block_floats(cfg), dtype=torch.float32, device=self.theta.device)
+        with self._guard():
+            _lib.check(_lib.lib().mg_cov_head_outputs(C.byref(cfg), _ptr(ws), ws.numel(), _ptr(block), self._s()))
+        return StepDists(self, cfg, block, bags)
 
     def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
         if self.theta.device.type != 'cuda':
@@ -223,11 +294,7 @@ class CovariantAC(AbstractActorCritic):
         N = self.observation_space.canvas_space.size
         pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
         B = len(observations)
-        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
-        assert acts.shape == (B, 6)
-        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
-        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
-            raise RuntimeError('index out of range in one-hot selection')  # to_one_hot's scatter_ error
+        acts = self._check_actions(actions, B)
         cfg = self._make_cfg(B, natoms)
         dev = self.theta.device
         d_pos = torch.from_numpy(pos).to(dev, non_blocking=True)
@@ -235,7 +302,13 @@ class CovariantAC(AbstractActorCritic):
         d_bag = torch.from_numpy(bags).to(dev, non_blocking=True)
         d_act = torch.from_numpy(acts).to(dev, non_blocking=True)
         out = _CovStep.apply(self.theta, self, cfg, d_pos, d_chg, d_bag, d_act)
-        return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
+        return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2],
+                'dists': self._dists(cfg, self._last_ws, d_bag)}
+
+    def evaluate_actions(self, observations: List[ObservationType], actions: np.ndarray) -> Dict[str, Any]:
+        """Action evaluation under the name BASELINE.json's north_star uses; the reference spells it
+        step(observations, actions) (base.py:17-19, ppo.py:26)."""
+        return self.step(observations, actions)
 
     # -- device-resident mini-batches (the PPO fast path: no autograd graph, no host sync) ---------
     def prepare_batch(self, observations: List[ObservationType], actions: np.ndarray, logp=None, adv=None,
@@ -244,11 +317,7 @@ class CovariantAC(AbstractActorCritic):
         N = self.observation_space.canvas_space.size
         pos, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
         B = len(observations)
-        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
-        assert acts.shape == (B, 6)
-        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
-        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
-            raise RuntimeError('index out of range in one-hot selection')
+        acts = self._check_actions(actions, B)
         dev = self.theta.device
         f64 = lambda x: None if x is None else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
         return DeviceBatch(self._make_cfg(B, natoms), torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
@@ -259,10 +328,7 @@ class CovariantAC(AbstractActorCritic):
         """Parse a whole rollout (the `data` dict of ppo.train) once; mini-batches are device gathers."""
         N = self.observation_space.canvas_space.size
         pos, charges, bags, natoms = parse_observations_host(data['obs'], self.zs, N)
-        acts = np.ascontiguousarray(np.asarray(data['act'], dtype=np.float32))
-        focus, element = np.rint(acts[:, 0]), np.rint(acts[:, 1])
-        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= len(self.zs):
-            raise RuntimeError('index out of range in one-hot selection')
+        acts = self._check_actions(data['act'], len(data['obs']))
         dev = self.theta.device
         f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
         return RolloutOnDevice(self, natoms, torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
@@ -283,9 +349,10 @@ class CovariantAC(AbstractActorCritic):
         """(3, B) float32: logp, ent, v -- no autograd graph."""
         ws = self._workspace(batch.cfg, slot)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
-        _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
-                                             _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
-                                             ws.numel(), _ptr(out), _stream()))
+        with self._guard():
+            _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos),
+                                                 _ptr(batch.charges), _ptr(batch.bags), _ptr(batch.actions),
+                                                 _ptr(self.leb), _ptr(ws), ws.numel(), _ptr(out), self._s()))
         self._last_ws = ws
         return out
 
@@ -301,15 +368,16 @@ class CovariantAC(AbstractActorCritic):
         B = batch.cfg.B
         stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
         gout = torch.empty(3, B, dtype=torch.float32, device=self.theta.device)
-        _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
-                                   vf_coef, entropy_coef, _ptr(stats), _ptr(gout), _stream()))
-        if loss_scale != 1.0:
-            gout.mul_(loss_scale)
-        if self.theta.grad is None:
-            self.theta.grad = torch.zeros_like(self.theta)
-        _lib.check(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
-                                       _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
-                                       _ptr(gout), _ptr(self.theta.grad), _stream()))
+        with self._guard():
+            _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
+                                       vf_coef, entropy_coef, _ptr(stats), _ptr(gout), self._s()))
+            if loss_scale != 1.0:
+                gout.mul_(loss_scale)
+            if self.theta.grad is None:
+                self.theta.grad = torch.zeros_like(self.theta)
+            _lib.check(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+                                           _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
+                                           ws.numel(), _ptr(gout), _ptr(self.theta.grad), self._s()))
         return stats
 
     def _step_sample(self, observations: List[ObservationType]) -> Dict[str, Any]:
@@ -326,16 +394,22 @@ class CovariantAC(AbstractActorCritic):
         acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
         seed = int(torch.randint(0, 2**62, (1, )).item())  # follows torch.manual_seed (util.set_seeds)
         mode = 1 if self.training else 2
-        _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
-                                            _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(), _ptr(acts),
-                                            _ptr(out), _stream()))
+        with self._guard():
+            _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
+                                                _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(),
+                                                _ptr(acts), _ptr(out), self._s()))
         self._last_ws = ws
+        dists = self._dists(cfg, ws, d_bag)
         host = acts.cpu().numpy()
         return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
-                'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': []}
+                'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
 
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""
         off, cnt = C.c_int64(), C.c_int64()
         _lib.check(_lib.lib().mg_cov_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))
         return self._last_ws.view(torch.float32)[off.value:off.value + cnt.value]
+
+    def workspace_view_int(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
+        """int32 view of a named index list of the last forward (natoms, atom_off, err, ...)."""
+        return self.workspace_view(name, cfg).view(torch.int32)

@@ -6,6 +6,7 @@
 #include "backward.inc"
 #include "ppo.inc"
 #include "internal.inc"
+#include "dists.inc"
 
 static bool g_tables_ready = false;
 static int ensure_tables() {
@@ -378,6 +379,34 @@ extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const floa
   HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
   SampleCtx smp = {seed, mode};
   return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
+}
+
+extern "C" int mg_cov_head_outputs(const mg_cov_cfg* c, const void* ws, size_t ws_bytes, float* out, void* stream) {
+  PLayout P;
+  int rc = build_layout(c, &P);
+  if (rc) return rc;
+  WS w;
+  rc = ws_build(c, P, const_cast<void*>(ws), &w, nullptr);
+  if (rc) return rc;
+  if (ws_bytes < w.bytes) MG_FAIL(MG_ENOMEM, "workspace %zu bytes < required %zu", ws_bytes, w.bytes);
+  HeadOutSrc src = {w.L.natoms, w.L.atom_off, w.logitF, w.logitE, w.dout, w.logz, {w.cond[0], w.cond[1], w.cond[2], w.cond[3], w.cond[4]}};
+  hipLaunchKernelGGL(k_head_outputs, dim3(c->B), dim3(256), 0, (hipStream_t)stream, c->B, c->N, c->Z, c->G, src, out);
+  LAUNCH_CHECK();
+  return MG_OK;
+}
+
+extern "C" int mg_so3_density(int32_t B, int64_t S, int32_t Bp, const float* coef, const float* points,
+                              int32_t has_beta, float beta, const float* logz, const uint8_t* empty, int32_t mode,
+                              float* out, void* stream) {
+  if (B < 1 || S < 0 || (Bp != B && Bp != 1)) MG_FAIL(MG_EINVAL, "points must be [S][B][3] or [S][1][3] (B=%d, Bp=%d)", B, Bp);
+  if (mode < 0 || mode > 2 || (mode == 2 && !has_beta)) MG_FAIL(MG_EINVAL, "mode %d not available", mode);
+  if (has_beta && !logz) MG_FAIL(MG_EINVAL, "logz is required for the exponential family");
+  if (S == 0) return MG_OK;
+  const long total = (long)S * B;
+  hipLaunchKernelGGL(k_so3_density, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, (long)S,
+                     Bp, coef, points, has_beta, beta, logz, empty, mode, out);
+  LAUNCH_CHECK();
+  return MG_OK;
 }
 
 #ifdef MG_TS
