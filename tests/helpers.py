@@ -53,3 +53,68 @@ def compact_vec(parts, atom_mask):
 def compact_edges(parts, edge_mask):
     """oracle SO3Scalar (B, N, N, C, 2) -> list over l of [TE, 2C]."""
     return [p[edge_mask].reshape(int(edge_mask.sum()), -1) for p in parts]
+
+
+# ---- the reference's agent property tests (tests/agents/covariant/test_agent.py:43-123) re-expressed ------------------
+def euler_rotation(alpha, beta, gamma):
+    """R = Rz(alpha) Ry(beta) Rz(gamma), the rotation sympy's Wigner D(alpha, beta, gamma) represents."""
+    def rz(a):
+        return np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+
+    def ry(a):
+        return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+
+    return rz(alpha) @ ry(beta) @ rz(gamma)
+
+
+_WIGNER = {}
+
+
+def wigner_d_sympy(alpha, beta, gamma, maxl=4):
+    """list over l of complex (2l+1, 2l+1) Wigner matrices D^l_{m m'}(alpha, beta, gamma) from
+    sympy.physics.quantum.spin.Rotation (independent of every table in this repo).  With R = euler_rotation(...):
+    Y_l(R x) = conj(D^l) Y_l(x), and the expansion coefficients of a field that rotates with R transform as a' = D a."""
+    key = (alpha, beta, gamma, maxl)
+    if key not in _WIGNER:
+        from sympy import N
+        from sympy.physics.quantum.spin import Rotation
+        out = []
+        for l in range(maxl + 1):
+            m = np.zeros((2 * l + 1, 2 * l + 1), dtype=np.complex128)
+            for a in range(-l, l + 1):
+                for b in range(-l, l + 1):
+                    m[a + l, b + l] = complex(N(Rotation.D(l, a, b, alpha, beta, gamma).doit()))
+            out.append(m)
+        _WIGNER[key] = out
+    return _WIGNER[key]
+
+
+def load_test_agent_molecules():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'test_agent_molecules.json')
+    return json.load(open(path))
+
+
+def molecule_observation(mol, setup, rotation=None):
+    """ObservationSpace.build(atoms, formula) of the reference (spaces.py:102-104) for one fixture molecule."""
+    zs, N = setup['zs'], setup['canvas_size']
+    pos = np.asarray(mol['positions'], dtype=np.float64)
+    if rotation is not None:
+        pos = pos @ rotation.T  # np.einsum('ij,...j->...i', rot_mat, positions), test_agent.py:52
+    canvas = [(zs.index(z), tuple(float(x) for x in p)) for z, p in zip(mol['numbers'], pos)]
+    canvas += [(0, (0.0, 0.0, 0.0))] * (N - len(canvas))
+    formula = dict((int(z), int(c)) for z, c in setup['formula'])
+    return tuple(canvas), tuple(formula.get(z, 0) for z in zs)
+
+
+def atomic_scalars_of(vec):
+    """so3_tools.AtomicScalars.forward (so3_tools.py:173-192) on a list over l of (..., tau, 2l+1, 2) tensors."""
+    blocks = [vec[0]]
+    for l, part in enumerate(vec):
+        s = torch.tensor([(-1.0)**m for m in range(-l, l + 1)], dtype=part.dtype, device=part.device)
+        sign = torch.stack([s, -s], dim=-1)
+        prod = (sign * part * part.flip(-2)).sum(dim=(-1, -2), keepdim=True)
+        nrm = (part * part).sum(dim=(-1, -2), keepdim=True)
+        blocks.append(torch.cat([prod, nrm], dim=-1))
+    return torch.cat(blocks, dim=-3).flatten(start_dim=-3)

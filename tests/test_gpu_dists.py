@@ -1,0 +1,202 @@
+"""`dists` of CovariantAC.step() (covariant/agent.py:325-331) on the HIP path, and the reference's own agent tests
+(tests/agents/covariant/test_agent.py:43-123) re-expressed on it: Wigner-D equivariance of the orientation
+coefficients to 1e-5, rotation invariance of the extrema of the density over a 100 000-point grid to 5e-3,
+invariance of AtomicScalars of the coefficients to 1e-5 -- same molecules, same configuration, Wigner matrices from
+sympy.  Plus Y_lm as the kernels compute it against scipy.special.sph_harm_y."""
+import numpy as np
+import pytest
+import torch
+
+from molgym_amd.agents.dists import fibonacci_grid
+from molgym_amd.synthetic import make_batch
+from tests.helpers import (atomic_scalars_of, euler_rotation, load_test_agent_molecules, make_pair,
+                           molecule_observation, rel_err, wigner_d_sympy)
+
+pytestmark = pytest.mark.gpu
+ANGLES = (0.3, 1.1, -0.7)
+
+
+def _scipy_ylm(xyz):
+    """(n, 25) complex 'qm' harmonics, q = l*l + l + m"""
+    from scipy.special import sph_harm_y
+    xyz = np.asarray(xyz, dtype=np.float64)
+    theta, phi = np.arccos(np.clip(xyz[:, 2], -1, 1)), np.arctan2(xyz[:, 1], xyz[:, 0])
+    return np.stack([sph_harm_y(l, m, theta, phi) for l in range(5) for m in range(-l, l + 1)], axis=1)
+
+
+def test_geometry_kernel_ylm_vs_scipy(built_lib):
+    """k_geom: conj Y_lm with 'unit' normalisation sqrt(4 pi / (2l+1)) of every relative position; Y_00 only on
+    the self edges (cormorant SphericalHarmonicsRel as wired at covariant/modules.py:52-56,102)."""
+    ac, ref, cfg = make_pair('cfg3', seed=3)
+    data = make_batch(9, cfg['canvas_size'], cfg['zs'], seed=8)
+    with torch.no_grad():
+        ac.step(data['obs'], data['act'])
+    from molgym_amd.agents.covariant import parse_observations_host
+    pos, charges, bags, natoms = parse_observations_host(data['obs'], cfg['zs'], cfg['canvas_size'])
+    ccfg = ac._make_cfg(len(data['obs']), natoms)
+    Y = ac.workspace_view('Y', ccfg)[:ccfg.TE * 50].view(ccfg.TE, 25, 2).double().cpu().numpy()
+    got = Y[..., 0] + 1j * Y[..., 1]
+    rel = np.concatenate([(pos[b, :n, None, :].astype(np.float64) - pos[b, None, :n, :]).reshape(-1, 3)
+                          for b, n in enumerate(natoms)])
+    r = np.linalg.norm(rel, axis=1)
+    unit = np.where(r[:, None] > 0, rel / np.maximum(r, 1e-30)[:, None], 0.0)
+    norm = np.concatenate([[np.sqrt(4 * np.pi / (2 * l + 1))] * (2 * l + 1) for l in range(5)])
+    want = np.conj(_scipy_ylm(np.where(r[:, None] > 0, unit, [[0, 0, 1.0]]))) * norm
+    want[r == 0, 1:] = 0.0
+    assert np.abs(got - want).max() < 2e-6
+    assert np.abs(ac.workspace_view('r', ccfg)[:ccfg.TE].double().cpu().numpy() - r).max() < 1e-6
+
+
+def test_so3_density_kernel_vs_scipy(built_lib):
+    from molgym_amd.agents.dists import SO3DensityHIP, SO3VecLite
+    g = torch.Generator().manual_seed(0)
+    B = 5
+    cond = SO3VecLite(torch.randn(B, 4, 2 * l + 1, 2, generator=g).cuda() for l in range(5))
+    pts = torch.randn(300, B, 3, generator=g)
+    pts[7] = 0.0  # a zero vector keeps Y_00 only
+    Yq = np.stack([_scipy_ylm(torch.nn.functional.normalize(pts[:, b].double(), dim=-1).numpy()) for b in range(B)], 1)
+    Yq[7, :, 1:] = 0.0
+    Yq[7, :, 0] = 0.28209479177387814
+    for beta in (None, 3.0):
+        log_z = torch.randn(B, generator=g).cuda() if beta is not None else None
+        empty = torch.tensor([False, True, False, False, True]).cuda()
+        dist = SO3DensityHIP(cond, beta, log_z, empty)
+        a = torch.cat([torch.complex(p[..., 0], p[..., 1]).sum(dim=1) for p in dist.coefficients], dim=-1)  # (B, 25)
+        s2 = np.abs(np.einsum('sbq,bq->sb', Yq, a.cpu().numpy().astype(np.complex128)))**2
+        if beta is None:
+            p = np.where(empty.cpu().numpy()[None, :], 1 / (4 * np.pi), s2)
+            want = np.log(np.maximum(p, 1e-10))
+            assert np.abs(dist.prob(pts.cuda()).cpu().numpy() - p).max() < 1e-5
+        else:
+            want = -beta * s2 - log_z.cpu().numpy()[None, :]
+            assert np.abs(dist.log_prob_unnormalized(pts.cuda()).cpu().numpy() + beta * s2).max() < 1e-4
+        got = dist.log_prob(pts.cuda()).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+        # broadcast form: one grid (S, 1, 3) for all samples -> (S, B)
+        grid = torch.tensor(fibonacci_grid(64), dtype=torch.float32).unsqueeze(1).cuda()
+        assert dist.log_prob(grid).shape == (64, B)
+        with pytest.raises(RuntimeError):  # test_spherical_distr.py:115-116
+            dist.log_prob(torch.zeros(10, B + 1, 3).cuda())
+
+
+@pytest.mark.parametrize('beta', ['cfg', None])
+def test_dists_match_oracle(built_lib, beta):
+    ac, ref, cfg = make_pair('cfg2', seed=4, beta=beta)
+    data = make_batch(17, cfg['canvas_size'], cfg['zs'], seed=6)
+    with torch.no_grad():
+        out = ac.step(data['obs'], data['act'])
+        exp = ref.step(data['obs'], data['act'], dtype=torch.float64, return_internals=True)
+    dists = out['dists']
+    assert len(dists) == 4
+    focus_dist, element_dist, distance_dist, so3_dist = dists
+    act = torch.as_tensor(data['act'], dtype=torch.float32).cuda()
+    got = [focus_dist.log_prob(act[:, 0].round().long()), element_dist.log_prob(act[:, 1].round().long()),
+           distance_dist.log_prob(act[:, 2]), so3_dist.log_prob(act[:, 3:6])]
+    for name, g, w in zip(('focus', 'element', 'distance', 'so3'), got, exp['logps']):
+        assert rel_err(g, w) < 2e-5, name
+    assert rel_err(focus_dist.entropy(), exp['ent_parts'][0], floor=1e-3) < 1e-4
+    assert rel_err(element_dist.entropy(), exp['ent_parts'][1], floor=1e-3) < 1e-4
+    # the four log-probabilities add up to what step() reports
+    assert rel_err(sum(got), out['logp']) < 1e-5
+    # coefficients = normalize_alms(cond_cov)
+    k = sum((p.sum(dim=-3)**2).sum(dim=(-1, -2)) for p in exp['cond_cov']).clamp(min=1e-10).sqrt().view(-1, 1, 1, 1)
+    for l in range(5):
+        assert so3_dist.coefficients.ells[l] == l
+        assert (so3_dist.coefficients[l].double().cpu() - exp['cond_cov'][l] / k).abs().max().item() < 1e-5
+
+
+def test_dists_survive_the_next_step(built_lib):
+    """the distributions are built from a packed copy of the head outputs, not from the (reused) workspace"""
+    ac, ref, cfg = make_pair('cfg2', seed=5)
+    d1 = make_batch(6, cfg['canvas_size'], cfg['zs'], seed=1)
+    d2 = make_batch(6, cfg['canvas_size'], cfg['zs'], seed=2)
+    with torch.no_grad():
+        first = ac.step(d1['obs'])
+        held = first['dists']
+        ac.step(d2['obs'])
+        again = ac.step(d1['obs'], first['a'].cpu().numpy())
+    a = held[-1].log_prob(first['a'][:, 3:6])
+    b = again['dists'][-1].log_prob(first['a'][:, 3:6])
+    assert torch.allclose(a, b, atol=1e-4, rtol=1e-5)
+
+
+@pytest.fixture(scope='module')
+def test_agent(built_lib):
+    """CovariantAgentTest.setUp (test_agent.py:23-41)"""
+    from molgym_amd.agents.covariant import CovariantAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    mols = load_test_agent_molecules()
+    su = mols['setup']
+    torch.manual_seed(0)
+    ac = CovariantAC(ObservationSpace(su['canvas_size'], su['zs']), ActionSpace([1]),
+                     min_max_distance=tuple(su['min_max_distance']), network_width=su['network_width'],
+                     bag_scale=su['bag_scale'], device='cuda:0', beta=su['beta'], maxl=4, num_cg_levels=3,
+                     num_channels_hidden=10, num_channels_per_element=4, num_gaussians=3)
+    return ac, mols, su
+
+
+def _so3_pair(ac, mol, su, sampled):
+    """so3_dist of the molecule and of its rotated copy; `sampled`: step(obs) with the seeds reset like the
+    reference test does (util.set_seeds(0) before each call), else action evaluation with fixed sub-actions"""
+    R = euler_rotation(*ANGLES)
+    res = []
+    for rot in (None, R):
+        obs = molecule_observation(mol, su, rot)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        with torch.no_grad():
+            if sampled:
+                res.append(ac.step([obs])['dists'][-1])
+            else:
+                res.append(ac.step([obs], np.array([[1, 1, 1.2, 0.0, 0.6, 0.8]]))['dists'][-1])
+    return res
+
+
+@pytest.mark.parametrize('sampled', [False, True])
+@pytest.mark.parametrize('name', ['h2o', 'ch3', 'ch4'])
+def test_rotations(test_agent, name, sampled):
+    """verify_alms, test_agent.py:43-61"""
+    ac, mols, su = test_agent
+    dist, dist_rot = _so3_pair(ac, mols[name], su, sampled)
+    D = [torch.tensor(np.stack([d.real, d.imag], axis=-1), dtype=torch.float32) for d in wigner_d_sympy(*ANGLES)]
+    rotated = dist.coefficients.apply_wigner(D)
+    for part1, part2 in zip(dist_rot.coefficients, rotated):
+        assert torch.max(torch.abs(part1 - part2)).item() < 1e-5
+    assert max(p.abs().max().item() for p in dist.coefficients[1:]) > 1e-3  # not vacuous: l >= 1 parts are populated
+
+
+@pytest.mark.parametrize('name', ['h2o', 'ch3', 'ch4'])
+def test_distribution(test_agent, name):
+    """verify_probs, test_agent.py:67-96"""
+    ac, mols, su = test_agent
+    dist, dist_rot = _so3_pair(ac, mols[name], su, True)
+    grid = torch.tensor(fibonacci_grid(100_000), dtype=torch.float32, device='cuda:0').unsqueeze(-2)
+    lp, lp_rot = dist.log_prob(grid), dist_rot.log_prob(grid)  # (samples, batches)
+    assert lp.shape == (100_000, 1)
+    assert torch.allclose(lp.max(dim=0).values, lp_rot.max(dim=0).values, atol=5e-3)
+    assert torch.allclose(lp.min(dim=0).values, lp_rot.min(dim=0).values, atol=5e-3)
+    # and the density integrates to one on the grid (test_spherical_distr.py:124-131)
+    assert abs(lp.exp().mean().item() * 4 * np.pi - 1.0) < 5e-3
+
+
+@pytest.mark.parametrize('name', ['h2o', 'ch3', 'ch4'])
+def test_invariance(test_agent, name):
+    """verify_invariance, test_agent.py:98-119"""
+    ac, mols, su = test_agent
+    dist, dist_rot = _so3_pair(ac, mols[name], su, True)
+    assert torch.allclose(atomic_scalars_of(dist.coefficients), atomic_scalars_of(dist_rot.coefficients), atol=1e-5)
+
+
+def test_sampling_and_argmax_of_the_returned_distribution(test_agent):
+    ac, mols, su = test_agent
+    with torch.no_grad():
+        dist = ac.step([molecule_observation(mols['h2o'], su)])['dists'][-1]
+    torch.manual_seed(1)
+    s = dist.sample(torch.Size((64, )))
+    assert s.shape == (64, 1, 3) and torch.allclose(s.norm(dim=-1), torch.ones(64, 1, device=s.device), atol=1e-5)
+    best = dist.argmax()
+    assert best.shape == (1, 3)
+    # the arg-max of 128 accepted draws sits near the top of the density
+    grid = torch.tensor(fibonacci_grid(4096), dtype=torch.float32, device='cuda:0').unsqueeze(1)
+    lp = dist.log_prob(grid)
+    assert dist.log_prob(best).item() > lp.max().item() - 0.5 * (lp.max() - lp.median()).item()
