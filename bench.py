@@ -139,14 +139,12 @@ def main_internal(args):
     torch.manual_seed(0)
     ac = SchNetAC(ObservationSpace(N, zs), ActionSpace(zs), (0.8, 1.8), 128, device='cuda:0')
     data = make_batch_internal(B, N, zs, seed=0)
-    batch = ac.make_batch(data['obs'], data['act'])
-    f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(ac.theta.device)
-    logp, adv, ret = f64(data['logp']), f64(data['adv']), f64(data['ret'])
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
     ac.theta.grad = torch.zeros_like(ac.theta)
 
     def step():
         ac.theta.grad.zero_()
-        return ac.ppo_minibatch(batch, logp, adv, ret, 0.2, 0.5, 0.01)
+        return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
 
     for _ in range(args.warmup):
         step()

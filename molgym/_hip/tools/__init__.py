@@ -1,0 +1,3 @@
+import molgym as _m
+
+__path__ = _m.search_path('tools')

@@ -1,9 +1,18 @@
-"""Actor-critic interface (mirror of /root/reference/molgym/agents/base.py:10-19)."""
+"""Actor-critic interface (mirror of /root/reference/molgym/agents/base.py:10-19) and what the two HIP agents share:
+ONE flat float32 parameter vector `theta` whose named slots are the reference module's state_dict entries."""
 import abc
-from typing import List, Optional
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
+
+try:
+    from torch.nn.modules.module import _IncompatibleKeys
+except ImportError:  # pragma: no cover
+    from collections import namedtuple
+    _IncompatibleKeys = namedtuple('IncompatibleKeys', ['missing_keys', 'unexpected_keys'])
 
 
 class AbstractActorCritic(torch.nn.Module, abc.ABC):
@@ -15,3 +24,84 @@ class AbstractActorCritic(torch.nn.Module, abc.ABC):
     @abc.abstractmethod
     def step(self, observations: List, actions: Optional[np.ndarray] = None) -> dict:
         raise NotImplementedError
+
+    def evaluate_actions(self, observations: List, actions: np.ndarray) -> dict:
+        """Action evaluation under the name BASELINE.json's north_star uses; the reference spells it
+        step(observations, actions) (base.py:17-19, ppo.py:26)."""
+        return self.step(observations, actions)
+
+
+class FlatThetaAgent(AbstractActorCritic):
+    """`self.theta` (nn.Parameter, flat) + `self.slot_table` (name -> (offset, shape), molgym_amd/layout.py).
+
+    state_dict() / load_state_dict() speak the REFERENCE module's keys -- one entry per tensor the reference agent
+    registers (covariant/agent.py:58-143, internal/agent.py:37-105) -- so a checkpoint written through state_dict()
+    by either implementation loads into the other; the flat vector itself is accepted too ({'theta': ...}).
+    Whole-module pickling (ModelIO, tools/model_util.py:82-100) keeps working: only caches are dropped."""
+
+    # entries of a reference checkpoint that carry no trainable state of this path (cormorant's fixed cut-off
+    # parameters and zero buffers, the agents' index helper buffers)
+    _IGNORED_SUFFIXES = ('soft_cut_rad', 'soft_cut_width', 'zero', 'channel_offsets', 'zs_tensor', 'leb')
+
+    def _slot(self, name: str, tensor: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shape = self.slot_table[name]
+        t = self.theta if tensor is None else tensor
+        return t[off:off + int(np.prod(shape))].view(shape)
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Named CLONES with the reference module's state_dict keys."""
+        t = self.theta.detach()
+        return {k: self._slot(k, t).clone() for k in self.slot_table}
+
+    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad():
+            for k in self.slot_table:
+                self._slot(k).copy_(sd[k].to(self.theta).reshape(self.slot_table[k][1]))
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        out = OrderedDict() if destination is None else destination
+        t = self.theta if keep_vars else self.theta.detach()
+        for k in self.slot_table:
+            out[prefix + k] = self._slot(k, t)
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = dict(state_dict)
+        if set(sd) == {'theta'}:
+            with torch.no_grad():
+                self.theta.copy_(sd['theta'].to(self.theta).reshape(-1))
+            return _IncompatibleKeys([], [])
+        missing = [k for k in self.slot_table if k not in sd]
+        unexpected = [k for k in sd if k not in self.slot_table and not k.endswith(self._IGNORED_SUFFIXES)]
+        bad = [k for k, (_, s) in self.slot_table.items() if k in sd and tuple(sd[k].shape) != tuple(s)]
+        if bad:
+            raise RuntimeError('size mismatch for ' + ', '.join(
+                f'{k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(self.slot_table[k][1])}' for k in bad))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'Error(s) in loading state_dict for {type(self).__name__}: missing keys {missing}, '
+                               f'unexpected keys {unexpected}')
+        with torch.no_grad():
+            for k in self.slot_table:
+                if k in sd:
+                    self._slot(k).copy_(sd[k].to(self.theta))
+        return _IncompatibleKeys(missing, unexpected)
+
+    # -- device plumbing ----------------------------------------------------------------------------------------------
+    def _guard(self):
+        """Every C call runs with the agent's device current: the library keeps per-device state (CG tables in
+        __constant__ memory, function attributes, side stream) keyed by hipGetDevice()."""
+        return torch.cuda.device(self.theta.device)
+
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.theta.device).cuda_stream)
+
+    def grad_norm_clip(self, max_norm: float = 0.0) -> torch.Tensor:
+        """||theta.grad||_2 as a 1-element device tensor (util.compute_gradient_norm, tools/util.py:61-69) and, if
+        max_norm > 0, theta.grad *= min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_, ppo.py:144) -- one C call on
+        the flat gradient instead of ~60 per-tensor kernels."""
+        from .. import _lib
+        norm = torch.empty(2, dtype=torch.float32, device=self.theta.device)
+        with self._guard():
+            _lib.check(_lib.lib().mg_grad_norm_clip(self.theta.numel(), C.c_void_p(self.theta.grad.data_ptr()),
+                                                    float(max_norm), C.c_void_p(norm.data_ptr()), self._s()))
+        return norm[:1]

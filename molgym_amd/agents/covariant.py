@@ -7,7 +7,6 @@ training path, ppo.py:26 -- runs in libmolgym_hip.so through one autograd node;
 there is no eager / CPU fallback.
 """
 import ctypes as C
-from collections import OrderedDict
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -16,14 +15,8 @@ import torch
 from .. import _lib, layout
 from ..lebedev import lebedev_table
 from ..spaces import ActionSpace, ObservationSpace, ObservationType
-from .base import AbstractActorCritic
+from .base import FlatThetaAgent
 from .dists import StepDists
-
-try:
-    from torch.nn.modules.module import _IncompatibleKeys
-except ImportError:  # very old / very new torch: same two fields
-    from collections import namedtuple
-    _IncompatibleKeys = namedtuple('IncompatibleKeys', ['missing_keys', 'unexpected_keys'])
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -113,7 +106,7 @@ class _CovStep(torch.autograd.Function):
         return grad, None, None, None, None, None, None
 
 
-class CovariantAC(AbstractActorCritic):
+class CovariantAC(FlatThetaAgent):
     def __init__(
         self,
         observation_space: ObservationSpace,
@@ -193,49 +186,6 @@ class CovariantAC(AbstractActorCritic):
             del self._pending_bias
         return theta
 
-    def export_state_dict(self) -> Dict[str, torch.Tensor]:
-        """Named tensors with the reference module's state_dict keys."""
-        t = self.theta.detach()
-        return {k: t[o:o + int(np.prod(s))].view(s).clone() for k, (o, s) in self.slot_table.items()}
-
-    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        with torch.no_grad():
-            for k, (o, s) in self.slot_table.items():
-                self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
-
-    # state_dict() / load_state_dict() speak the REFERENCE module's keys (one entry per tensor the reference's
-    # CovariantAC registers, agent.py:58-143; names in layout.py), so a checkpoint written through state_dict() by
-    # either implementation loads into the other.  The flat vector itself is also accepted ({'theta': ...}).
-    _IGNORED_SUFFIXES = ('soft_cut_rad', 'soft_cut_width', 'zero', 'channel_offsets', 'zs_tensor', 'leb')
-
-    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
-        out = OrderedDict() if destination is None else destination
-        t = self.theta if keep_vars else self.theta.detach()
-        for k, (o, s) in self.slot_table.items():
-            out[prefix + k] = t[o:o + int(np.prod(s))].view(s)
-        return out
-
-    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        sd = dict(state_dict)
-        if set(sd) == {'theta'}:
-            with torch.no_grad():
-                self.theta.copy_(sd['theta'].to(self.theta).reshape(-1))
-            return _IncompatibleKeys([], [])
-        missing = [k for k in self.slot_table if k not in sd]
-        unexpected = [k for k in sd if k not in self.slot_table and not k.endswith(self._IGNORED_SUFFIXES)]
-        bad_shape = [k for k, (o, s) in self.slot_table.items() if k in sd and tuple(sd[k].shape) != tuple(s)]
-        if bad_shape:
-            raise RuntimeError('size mismatch for ' + ', '.join(
-                f'{k}: checkpoint {tuple(sd[k].shape)} vs model {self.slot_table[k][1]}' for k in bad_shape))
-        if strict and (missing or unexpected):
-            raise RuntimeError(f'Error(s) in loading state_dict for CovariantAC: missing keys {missing}, '
-                               f'unexpected keys {unexpected}')
-        with torch.no_grad():
-            for k, (o, s) in self.slot_table.items():
-                if k in sd:
-                    self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
-        return _IncompatibleKeys(missing, unexpected)
-
     # -- batch ----------------------------------------------------------------------------------
     def _make_cfg(self, B: int, natoms: np.ndarray) -> _lib.CovCfg:
         cfg = _lib.CovCfg()
@@ -249,14 +199,6 @@ class CovariantAC(AbstractActorCritic):
         cfg.bag_scale = float(self.bag_scale)
         cfg.min_distance, cfg.max_distance = float(self.min_distance), float(self.max_distance)
         return cfg
-
-    def _guard(self):
-        """every C call runs with the agent's device current: the library keeps per-device state (CG tables in
-        __constant__ memory, function attributes, side stream) keyed by hipGetDevice()."""
-        return torch.cuda.device(self.theta.device)
-
-    def _s(self):
-        return _stream(self.theta.device)
 
     def to_action_space(self, action: np.ndarray, observation: ObservationType):
         """agent.py:147-163 without the ase round trip: position = focused atom + distance * direction, where the
@@ -305,11 +247,6 @@ class CovariantAC(AbstractActorCritic):
         return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2],
                 'dists': self._dists(cfg, self._last_ws, d_bag)}
 
-    def evaluate_actions(self, observations: List[ObservationType], actions: np.ndarray) -> Dict[str, Any]:
-        """Action evaluation under the name BASELINE.json's north_star uses; the reference spells it
-        step(observations, actions) (base.py:17-19, ppo.py:26)."""
-        return self.step(observations, actions)
-
     # -- device-resident mini-batches (the PPO fast path: no autograd graph, no host sync) ---------
     def prepare_batch(self, observations: List[ObservationType], actions: np.ndarray, logp=None, adv=None,
                       ret=None) -> 'DeviceBatch':
@@ -330,7 +267,7 @@ class CovariantAC(AbstractActorCritic):
         pos, charges, bags, natoms = parse_observations_host(data['obs'], self.zs, N)
         acts = self._check_actions(data['act'], len(data['obs']))
         dev = self.theta.device
-        f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+        f64 = lambda x: x.to(dev) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
         return RolloutOnDevice(self, natoms, torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
                                torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(data['logp']),
                                f64(data['adv']), f64(data['ret']))

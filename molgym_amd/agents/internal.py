@@ -17,7 +17,7 @@ import torch
 
 from .. import _lib, layout
 from ..spaces import ActionSpace, ObservationSpace, ObservationType
-from .base import AbstractActorCritic
+from .base import FlatThetaAgent
 from .covariant import _ptr, _stream, parse_observations_host
 
 
@@ -54,9 +54,29 @@ def place_new_atoms(pos: np.ndarray, natoms: np.ndarray, focus: np.ndarray, dist
 
 
 class IntBatch:
-    def __init__(self, cfg, mol_off, edge_off, molZ, molpos, bags, actions):
+    def __init__(self, cfg, mol_off, edge_off, molZ, molpos, bags, actions, logp=None, adv=None, ret=None):
         self.cfg, self.mol_off, self.edge_off, self.molZ, self.molpos = cfg, mol_off, edge_off, molZ, molpos
         self.bags, self.actions = bags, actions
+        self.logp, self.adv, self.ret = logp, adv, ret
+
+
+class IntRollout:
+    """A rollout prepared for `ppo.train`'s device path.  The ragged 3B-molecule batch of a mini-batch depends on
+    which samples are in it (z-matrix placement per sample, molecule / pair offsets), so it is assembled on the host
+    per mini-batch; the float64 loss inputs are parked in HBM once and gathered on the device."""
+
+    def __init__(self, ac, data):
+        dev = ac.theta.device
+        self.ac, self.obs, self.act = ac, data['obs'], np.asarray(data['act'])
+        f64 = lambda x: x.to(dev) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+        self.logp, self.adv, self.ret = f64(data['logp']), f64(data['adv']), f64(data['ret'])
+
+    def minibatch(self, indices: np.ndarray) -> IntBatch:
+        idx = np.asarray(indices, dtype=np.int64)
+        batch = self.ac.make_batch([self.obs[i] for i in idx], self.act[idx])
+        d_idx = torch.from_numpy(idx).to(self.logp.device)
+        batch.logp, batch.adv, batch.ret = (x.index_select(0, d_idx) for x in (self.logp, self.adv, self.ret))
+        return batch
 
 
 class _IntStep(torch.autograd.Function):
@@ -67,9 +87,10 @@ class _IntStep(torch.autograd.Function):
         _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=theta.device)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=theta.device)
-        _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
-                                      _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
-                                      _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        with torch.cuda.device(theta.device):
+            _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
+                                          _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
+                                          _ptr(ws), nbytes.value, _ptr(out), _stream(theta.device)))
         ctx.save_for_backward(theta, ws)
         ctx.batch = batch
         ac._last_ws = ws
@@ -81,13 +102,15 @@ class _IntStep(torch.autograd.Function):
         b = ctx.batch
         grad = torch.zeros_like(theta)
         gout = gout.contiguous()
-        _lib.check(_lib.lib().mg_int_backward(C.byref(b.cfg), _ptr(theta), _ptr(b.mol_off), _ptr(b.edge_off),
-                                              _ptr(b.molZ), _ptr(b.molpos), _ptr(b.bags), _ptr(b.actions), _ptr(ws),
-                                              ws.numel(), _ptr(gout), _ptr(grad), _stream()))
+        with torch.cuda.device(theta.device):
+            _lib.check(_lib.lib().mg_int_backward(C.byref(b.cfg), _ptr(theta), _ptr(b.mol_off), _ptr(b.edge_off),
+                                                  _ptr(b.molZ), _ptr(b.molpos), _ptr(b.bags), _ptr(b.actions),
+                                                  _ptr(ws), ws.numel(), _ptr(gout), _ptr(grad),
+                                                  _stream(theta.device)))
         return grad, None, None
 
 
-class SchNetAC(AbstractActorCritic):
+class SchNetAC(FlatThetaAgent):
     def __init__(self, observation_space: ObservationSpace, action_space: ActionSpace,
                  min_max_distance: Tuple[float, float], network_width: int, device=None):
         super().__init__(observation_space, action_space)
@@ -125,15 +148,6 @@ class SchNetAC(AbstractActorCritic):
                 torch.nn.init.orthogonal_(view)
             # every bias starts at zero
         return theta
-
-    def export_state_dict(self) -> Dict[str, torch.Tensor]:
-        t = self.theta.detach()
-        return {k: t[o:o + int(np.prod(s))].view(s).clone() for k, (o, s) in self.slot_table.items()}
-
-    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        with torch.no_grad():
-            for k, (o, s) in self.slot_table.items():
-                self.theta[o:o + int(np.prod(s))].copy_(sd[k].reshape(-1).to(self.theta))
 
     def make_batch(self, observations: List[ObservationType], actions: np.ndarray) -> IntBatch:
         N, B = self.num_atoms, len(observations)
@@ -187,10 +201,10 @@ class SchNetAC(AbstractActorCritic):
             return None  # the reference builds an empty ase.Atoms here; this agent never stops (agent.py:190-191)
         focus, element = int(round(focus)), int(round(element))
         sign = -1.0 if int(round(kappa)) else 1.0
-        atoms, _ = self.observation_space.parse_positions(observation)
+        atoms = [xyz for label, xyz in observation[0] if self.zs[label] != 0]  # ObservationSpace.parse drops nulls
         n = len(atoms)
         pos = np.zeros((1, max(self.num_atoms, 1), 3))
-        for k, (_, xyz) in enumerate(atoms):
+        for k, xyz in enumerate(atoms):
             pos[0, k] = xyz
         new = place_new_atoms(pos, np.array([n]), np.array([focus]), np.array([distance]), np.array([angle]),
                               np.array([sign * dihedral]))[0]
@@ -203,29 +217,45 @@ class SchNetAC(AbstractActorCritic):
         _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.theta.device)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
-        _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
-                                      _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
-                                      _ptr(ws), nbytes.value, _ptr(out), _stream()))
+        with self._guard():
+            _lib.check(lib.mg_int_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off),
+                                          _ptr(batch.edge_off), _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags),
+                                          _ptr(batch.actions), _ptr(ws), nbytes.value, _ptr(out), self._s()))
         self._last_ws = ws
         return out, ws
 
-    def ppo_minibatch(self, batch: IntBatch, logp, adv, ret, clip_ratio: float, vf_coef: float,
-                      entropy_coef: float) -> torch.Tensor:
+    def prepare_rollout(self, data: Dict[str, Any]) -> IntRollout:
+        return IntRollout(self, data)
+
+    def prepare_batch(self, observations, actions, logp=None, adv=None, ret=None) -> IntBatch:
+        batch = self.make_batch(observations, actions)
+        dev = self.theta.device
+        f64 = lambda x: None if x is None else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
+        batch.logp, batch.adv, batch.ret = f64(logp), f64(adv), f64(ret)
+        return batch
+
+    def ppo_minibatch(self, batch: IntBatch, clip_ratio: float, vf_coef: float, entropy_coef: float,
+                      loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
         """forward + float64 PPO loss + hand-written backward on the device (ppo.py:124-131), gradients accumulated
-        into theta.grad; `logp / adv / ret` are float64 device tensors.  Returns the 6 loss statistics."""
+        into theta.grad (scaled by `loss_scale`: the data-parallel B_local / B_global); same signature as
+        CovariantAC.ppo_minibatch.  Returns the 6 loss statistics (float64 device tensor, no sync)."""
         lib = _lib.lib()
         out, ws = self._forward_nograd(batch)
         B = batch.cfg.B
         dev = self.theta.device
         stats = torch.empty(6, dtype=torch.float64, device=dev)
         gout = torch.empty(3, B, dtype=torch.float32, device=dev)
-        _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(logp), _ptr(adv), _ptr(ret), clip_ratio, vf_coef, entropy_coef,
-                                   _ptr(stats), _ptr(gout), _stream()))
-        if self.theta.grad is None:
-            self.theta.grad = torch.zeros_like(self.theta)
-        _lib.check(lib.mg_int_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
-                                       _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions),
-                                       _ptr(ws), ws.numel(), _ptr(gout), _ptr(self.theta.grad), _stream()))
+        with self._guard():
+            _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
+                                       vf_coef, entropy_coef, _ptr(stats), _ptr(gout), self._s()))
+            if loss_scale != 1.0:
+                gout.mul_(loss_scale)
+            if self.theta.grad is None:
+                self.theta.grad = torch.zeros_like(self.theta)
+            _lib.check(lib.mg_int_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off),
+                                           _ptr(batch.edge_off), _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags),
+                                           _ptr(batch.actions), _ptr(ws), ws.numel(), _ptr(gout),
+                                           _ptr(self.theta.grad), self._s()))
         return stats
 
     def _ws_view(self, cfg, ws: torch.Tensor, name: str) -> torch.Tensor:

@@ -1,25 +1,34 @@
-"""PPO update driver on the HIP hot path.
+"""PPO driver on the HIP hot path.
 
-Mirror of /root/reference/molgym/ppo.py:18-161 (compute_loss, get_batch_generator,
-collect_data_batch, compute_mean_dict, train) with the same names, arguments and
-return values.  `train` keeps the reference's semantics exactly -- gradients are
-accumulated over every mini-batch of the rollout and ONE optimizer step is taken
-per epoch (ppo.py:117-146) -- but each mini-batch runs as forward -> float64 loss
--> hand-written backward on the device with no host synchronisation.
+Mirror of /root/reference/molgym/ppo.py (compute_loss :18-63, get_batch_generator :66-74, collect_data_batch :77-89,
+compute_mean_dict :92-95, train :99-161, batch_rollout :164-218, compute_buffer_stats :221-227, batch_ppo :230-377)
+with the same names, arguments and return values.
 
-Data parallel (new; the reference is single-process): when torch.distributed is
-initialised every rank holds the same rollout `data`, draws the same permutation
-(same numpy seed), takes its contiguous slice of every mini-batch, scales its
-gradient by B_local / B_global and the flat gradient vector is summed ONCE per
-epoch (one RCCL all-reduce of ~0.75 MB) before the norm / clip / step, so all
-ranks take identical steps.
+`train` keeps the reference's semantics exactly -- gradients are accumulated over every mini-batch of the rollout
+and ONE optimizer step is taken per epoch (ppo.py:117-146) -- but for the HIP agents each mini-batch runs as
+forward -> float64 loss -> hand-written backward on the device with no host synchronisation (`ppo_minibatch`), the
+gradient norm / clip is one C call on the flat gradient (`mg_grad_norm_clip`), and the per-epoch host traffic is ONE
+copy of 7 doubles.  An agent without that device path (anything with just `step`) goes through `compute_loss` +
+autograd, mini-batch by mini-batch, like the reference.  Both ways share one sharding / reduction code path.
+
+Data parallel (new; the reference is single-process).  When torch.distributed is initialised:
+  * rollout: every rank steps its OWN environments; `gather_rollout` standardises the advantages over all ranks
+    (buffer.py:104-110 needs the global mean / std: two tiny float64 all-reduces) and all-gathers the rollout, so
+    every rank holds the same `data`, ordered by rank -- exactly the buffer a single process driving all the
+    environments would have merged;
+  * update: rank 0's permutation is broadcast each epoch, every rank takes its contiguous slice of every
+    mini-batch with gradient scale B_local / B_global (an empty slice contributes zero), and the flat gradient is
+    summed ONCE per epoch (one ~0.75 MB RCCL all-reduce) before norm / clip / step, so all ranks take identical
+    Adam steps; the 6 loss statistics ride in one 48-byte float64 all-reduce.
 """
 import logging
 import time
-from typing import Dict, Iterator, List, Sequence, Tuple
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from .buffer import DynamicPPOBuffer, PPOBufferContainer
 
 KEYS = ('policy_loss', 'entropy_loss', 'vf_loss', 'total_loss', 'approx_kl', 'clip_fraction')
 
@@ -29,6 +38,10 @@ def _dist():
     if dist.is_available() and dist.is_initialized():
         return dist, dist.get_rank(), dist.get_world_size()
     return None, 0, 1
+
+
+def to_numpy(t) -> np.ndarray:
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
 
 
 def compute_loss(ac, data: dict, clip_ratio: float, vf_coef: float, entropy_coef: float,
@@ -69,6 +82,8 @@ def collect_data_batch(data: Dict[str, Sequence], indices: np.ndarray) -> Dict[s
     for key, value in data.items():
         if isinstance(value, np.ndarray):
             batch[key] = value[indices]
+        elif torch.is_tensor(value):  # get_data(device=...) hands over float64 device tensors
+            batch[key] = value[torch.as_tensor(np.asarray(indices, dtype=np.int64), device=value.device)]
         elif isinstance(value, list):
             batch[key] = [value[i] for i in indices]
     return batch
@@ -86,67 +101,122 @@ def compute_gradient_norm(parameters) -> float:
     return torch.norm(torch.stack([torch.norm(p.grad.detach(), 2) for p in ps]), 2).item()
 
 
+# ---- one epoch's mini-batches: device path / autograd path behind one interface ------------------------------------
+class _DeviceRunner:
+    """Agents with `prepare_rollout` + `ppo_minibatch` (CovariantAC, SchNetAC): the rollout is parsed once and parked
+    in HBM, a mini-batch is a device gather + forward / loss / backward launches, statistics stay on the device.
+    The mini-batches of one epoch are independent given theta (their gradients only accumulate) and a small
+    mini-batch leaves most of the chip idle: up to 3 are kept in flight on separate HIP streams."""
+
+    def __init__(self, ac, data, mini_batch_size, hp):
+        self.ac, self.hp = ac, hp
+        self.rollout = ac.prepare_rollout(data)
+        self.dev = next(ac.parameters()).device
+        self.streams = []
+        if self.dev.type == 'cuda' and len(data['obs']) > mini_batch_size:
+            self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+
+    def begin_epoch(self):
+        for p in self.ac.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream(self.dev))
+
+    def run(self, mb_index: int, local: np.ndarray, scale: float) -> torch.Tensor:
+        if len(local) == 0:  # this rank's slice of a small remainder mini-batch
+            return torch.zeros(6, dtype=torch.float64, device=self.dev)
+        mb = self.rollout.minibatch(local)
+        if not self.streams:
+            return self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale) * scale
+        slot = mb_index % len(self.streams)
+        st = self.streams[slot]
+        st.wait_stream(torch.cuda.current_stream(self.dev))  # the gather above ran there
+        with torch.cuda.stream(st):
+            stats = self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale, slot=slot) * scale
+        for t in vars(mb).values():
+            if torch.is_tensor(t):
+                t.record_stream(st)
+        stats.record_stream(st)
+        return stats
+
+    def end_epoch(self):
+        for st in self.streams:
+            torch.cuda.current_stream(self.dev).wait_stream(st)
+
+
+class _AutogradRunner:
+    """Any AbstractActorCritic: compute_loss + loss.backward() per mini-batch (ppo.py:122-131)."""
+
+    def __init__(self, ac, data, mini_batch_size, hp, device=None):
+        self.ac, self.data, self.hp, self.device = ac, data, hp, device
+        self.dev = next(ac.parameters()).device
+
+    def begin_epoch(self):
+        pass
+
+    def run(self, mb_index: int, local: np.ndarray, scale: float) -> torch.Tensor:
+        if len(local) == 0:  # mean over zero samples is NaN: an empty slice contributes nothing
+            return torch.zeros(6, dtype=torch.float64, device=self.dev)
+        loss, info = compute_loss(self.ac, collect_data_batch(self.data, local), *self.hp, self.device)
+        (loss * scale).backward()
+        return torch.tensor([info[k] for k in KEYS], dtype=torch.float64, device=self.dev) * scale
+
+    def end_epoch(self):
+        pass
+
+
+def _epoch_batches(num_samples: int, mini_batch_size: int, dist, rank: int) -> List[np.ndarray]:
+    batches = list(get_batch_generator(np.arange(num_samples), mini_batch_size))  # every rank advances its numpy RNG
+    if dist is not None:  # ... but rank 0's permutation is the one everybody uses
+        box = [batches if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        batches = box[0]
+    return batches
+
+
 def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_ratio: float, target_kl: float,
           vf_coef: float, entropy_coef: float, gradient_clip: float, max_num_steps: int, device=None) -> dict:
     infos: Dict[str, float] = {}
     start_time = time.time()
     dist, rank, world = _dist()
-    fast = hasattr(ac, 'prepare_rollout')
-    rollout = ac.prepare_rollout(data) if fast else None
-    # The mini-batches of one epoch are independent given theta (their gradients only accumulate), and a small
-    # mini-batch leaves most of the chip idle: keep up to 3 of them in flight on separate HIP streams.
-    streams = []
-    if fast and len(data['obs']) > mini_batch_size:
-        streams = [torch.cuda.Stream(device=ac.theta.device) for _ in range(3)]
+    hp = (clip_ratio, vf_coef, entropy_coef)
+    device_path = hasattr(ac, 'prepare_rollout') and hasattr(ac, 'ppo_minibatch')
+    runner = _DeviceRunner(ac, data, mini_batch_size, hp) if device_path else \
+        _AutogradRunner(ac, data, mini_batch_size, hp, device)
+    flat = hasattr(ac, 'grad_norm_clip') and next(ac.parameters()).device.type == 'cuda'
+    num_samples = len(data['obs'])
     num_epochs = 0
     for i in range(max_num_steps):
         optimizer.zero_grad()
-        if fast and ac.theta.grad is None:
-            ac.theta.grad = torch.zeros_like(ac.theta)
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-        batch_stats, weights = [], []
-        for mb_index, batch_indices in enumerate(get_batch_generator(np.arange(len(data['obs'])), mini_batch_size)):
+        runner.begin_epoch()
+        batch_stats = []
+        for mb_index, batch_indices in enumerate(_epoch_batches(num_samples, mini_batch_size, dist, rank)):
             n_glob = len(batch_indices)
             lo, hi = (rank * n_glob) // world, ((rank + 1) * n_glob) // world
-            local = batch_indices[lo:hi]
-            if fast:
-                if len(local):
-                    mb = rollout.minibatch(local)
-                    if streams:
-                        slot = mb_index % len(streams)
-                        streams[slot].wait_stream(torch.cuda.current_stream())  # the gather above ran there
-                        with torch.cuda.stream(streams[slot]):
-                            stats = ac.ppo_minibatch(mb, clip_ratio, vf_coef, entropy_coef,
-                                                     loss_scale=len(local) / n_glob, slot=slot)
-                            stats = stats * (len(local) / n_glob)
-                        for t in (mb.pos, mb.charges, mb.bags, mb.actions, mb.logp, mb.adv, mb.ret, stats):
-                            t.record_stream(streams[slot])
-                        batch_stats.append(stats)
-                    else:
-                        stats = ac.ppo_minibatch(mb, clip_ratio, vf_coef, entropy_coef,
-                                                 loss_scale=len(local) / n_glob)
-                        batch_stats.append(stats * (len(local) / n_glob))
-                else:
-                    batch_stats.append(torch.zeros(6, dtype=torch.float64, device=ac.theta.device))
-            else:
-                loss, info = compute_loss(ac, collect_data_batch(data, local), clip_ratio, vf_coef, entropy_coef, device)
-                (loss * (len(local) / n_glob)).backward()
-                batch_stats.append(torch.tensor([info[k] for k in KEYS], dtype=torch.float64) * (len(local) / n_glob))
-        for st in streams:
-            torch.cuda.current_stream().wait_stream(st)
+            batch_stats.append(runner.run(mb_index, batch_indices[lo:hi], (hi - lo) / n_glob))
+        runner.end_epoch()
         stats = torch.stack(batch_stats).mean(dim=0)  # mean of mini-batch means (ppo.py:92-95)
         if dist is not None:
             dist.all_reduce(stats)
             for p in ac.parameters():
-                if p.grad is not None:
-                    dist.all_reduce(p.grad)
-        loss_info = dict(zip(KEYS, stats.tolist()))
-        loss_info['grad_norm'] = compute_gradient_norm(ac.parameters())
+                if p.grad is None:  # a rank whose every slice was empty still takes part in the reduction
+                    p.grad = torch.zeros_like(p)
+                dist.all_reduce(p.grad)
+        if flat:
+            host = torch.cat([stats, ac.grad_norm_clip(0.0).double()]).tolist()  # the epoch's only device -> host copy
+            loss_info = dict(zip(KEYS, host[:6]))
+            loss_info['grad_norm'] = host[6]
+        else:
+            loss_info = dict(zip(KEYS, stats.tolist()))
+            loss_info['grad_norm'] = compute_gradient_norm(ac.parameters())
         if loss_info['approx_kl'] > 1.5 * target_kl:
             logging.debug(f'Early stopping at step {i} for reaching max KL.')
             break
-        torch.nn.utils.clip_grad_norm_(ac.parameters(), max_norm=gradient_clip)
+        if flat:
+            ac.grad_norm_clip(gradient_clip)
+        else:
+            torch.nn.utils.clip_grad_norm_(ac.parameters(), max_norm=gradient_clip)
         optimizer.step()
         optimizer.zero_grad()
         num_epochs += 1
@@ -158,3 +228,211 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
                      f'entropy loss={infos["entropy_loss"]:.3f}, total loss={infos["total_loss"]:.3f}, '
                      f'num steps={num_epochs}')
     return infos
+
+
+# ---- rollout ---------------------------------------------------------------------------------------------------------
+def _host_predictions(predictions: dict) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(a, v, logp) of one step() on the host with ONE device -> host copy."""
+    a, v, logp = predictions['a'], predictions['v'], predictions['logp']
+    if torch.is_tensor(a) and a.is_cuda:
+        packed = torch.cat([a.detach().float(), v.detach().float().unsqueeze(1), logp.detach().float().unsqueeze(1)],
+                           dim=1).cpu().numpy()
+        width = a.shape[1]
+        return packed[:, :width], packed[:, width], packed[:, width + 1]
+    return to_numpy(a), to_numpy(v), to_numpy(logp)
+
+
+def batch_rollout(ac, envs, buffer_container: PPOBufferContainer, num_steps: Optional[int] = None,
+                  num_episodes: Optional[int] = None, pipeline: int = 2) -> dict:
+    """ppo.py:164-218.  With an `AsyncEnvContainer` (anything with `groups`) and a fixed number of steps the
+    environments are split into `pipeline` groups living on disjoint worker processes and the loop is software-
+    pipelined: while the workers step group g on the host (reward = 3 PM6 single points per environment), the GPU
+    evaluates the policy for the next group.  Environments are independent, so every environment sees the same
+    sequence of (observation -> action -> next observation) pairs either way."""
+    assert num_steps is not None or num_episodes is not None
+    start_time = time.time()
+    if num_steps is not None and num_episodes is None and pipeline > 1 and hasattr(envs, 'groups') \
+            and len(envs.groups(pipeline)) > 1:
+        _rollout_pipelined(ac, envs, buffer_container, num_steps, pipeline)
+    else:
+        _rollout_serial(ac, envs, buffer_container, num_steps, num_episodes)
+    return {
+        'time': time.time() - start_time,
+        'return_mean': np.mean(buffer_container.episodic_returns).item(),
+        'return_std': np.std(buffer_container.episodic_returns).item(),
+        'episode_length_mean': np.mean(buffer_container.episode_lengths).item(),
+        'episode_length_std': np.std(buffer_container.episode_lengths).item(),
+    }
+
+
+def _rollout_serial(ac, envs, container, num_steps, num_episodes):
+    if num_steps is not None:
+        assert num_steps % envs.get_size() == 0
+        num_iters = num_steps // envs.get_size()
+    else:
+        num_iters = np.inf
+    if num_episodes is not None:
+        assert envs.get_size() == 1
+    else:
+        num_episodes = np.inf
+    counter = 0
+    observations = envs.reset()
+    while counter < num_iters and container.get_num_episodes() < num_episodes:
+        predictions = ac.step(observations)
+        next_observations, rewards, terminals, _ = envs.step(predictions['actions'])
+        a, v, logp = _host_predictions(predictions)
+        container.store(observations=observations, actions=a, rewards=rewards, next_observations=next_observations,
+                        terminals=terminals, values=v, logps=logp)
+        observations = envs.reset_if_terminal(next_observations, terminals)  # a valid next observation either way
+        if counter == num_iters - 1:
+            _, v, _ = _host_predictions(ac.step(observations))
+            container.finish_paths(v)  # bootstrap the cut-off paths; finished ones are untouched
+        counter += 1
+
+
+def _rollout_pipelined(ac, envs, container, num_steps, pipeline):
+    assert num_steps % envs.get_size() == 0
+    num_iters = num_steps // envs.get_size()
+    groups = envs.groups(pipeline)
+    obs = [envs.reset(g) for g in groups]
+    pending = [None] * len(groups)  # (ticket, host predictions) of the step in flight per group
+
+    def launch(k):
+        predictions = ac.step(obs[k])
+        pending[k] = (envs.step_async(predictions['actions'], groups[k]), _host_predictions(predictions))
+
+    for k in range(len(groups)):
+        launch(k)  # group k+1's policy evaluation overlaps group k's environment step
+    for it in range(num_iters):
+        for k, g in enumerate(groups):
+            ticket, (a, v, logp) = pending[k]
+            next_obs, rewards, terminals, _ = envs.step_wait(ticket)
+            container.store(observations=obs[k], actions=a, rewards=rewards, next_observations=next_obs,
+                            terminals=terminals, values=v, logps=logp, env_indices=g)
+            obs[k] = envs.reset_if_terminal(next_obs, terminals, g)
+            if it < num_iters - 1:
+                launch(k)
+            else:
+                _, v, _ = _host_predictions(ac.step(obs[k]))
+                container.finish_paths(v, env_indices=g)
+
+
+def compute_buffer_stats(buffer: DynamicPPOBuffer) -> Dict[str, float]:
+    return {
+        'value_mean': np.mean(buffer.val_buf).item(),
+        'value_std': np.std(buffer.val_buf).item(),
+        'logp_mean': np.mean(buffer.logp_buf).item(),
+        'logp_std': np.std(buffer.logp_buf).item(),
+    }
+
+
+def gather_rollout(buffer: DynamicPPOBuffer) -> dict:
+    """`buffer.get_data()` of the rollout of ALL ranks (every rank stepped its own environments): advantages
+    standardised with the global population mean / std (buffer.py:104-110; two float64 all-reduces: [sum, n], then
+    [sum of squared deviations] -- the same two-pass form numpy uses), rollout all-gathered in rank order.  Without
+    torch.distributed this is `buffer.get_data()`."""
+    dist, rank, world = _dist()
+    if dist is None:
+        return buffer.get_data()
+    assert buffer.is_finished()
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    adv = np.array(buffer.adv_buf, dtype=np.float64)
+    first = torch.tensor([adv.sum(), float(len(adv))], dtype=torch.float64, device=dev)
+    dist.all_reduce(first)
+    mean = first[0].item() / first[1].item()
+    second = torch.tensor([np.square(adv - mean).sum()], dtype=torch.float64, device=dev)
+    dist.all_reduce(second)
+    std = np.sqrt(second.item() / first[1].item())
+    local = dict(obs=buffer.obs_buf, act=np.array(buffer.act_buf), ret=np.array(buffer.ret_buf),
+                 adv=(adv - mean) / std, logp=np.array(buffer.logp_buf))
+    parts: List[Optional[dict]] = [None] * world
+    dist.all_gather_object(parts, local)
+    return dict(obs=[o for p in parts for o in p['obs']],
+                **{k: np.concatenate([p[k] for p in parts]) for k in ('act', 'ret', 'adv', 'logp')})
+
+
+def batch_ppo(
+    envs,
+    eval_envs,
+    ac,
+    optimizer,
+    gamma=0.99,
+    start_num_steps=0,
+    max_num_steps=4096,
+    num_steps_per_iter=200,
+    mini_batch_size=64,
+    clip_ratio=0.2,
+    vf_coef=0.5,
+    entropy_coef=0.0,
+    max_num_train_iters=80,
+    lam=0.97,
+    target_kl=0.01,
+    gradient_clip=0.5,
+    save_freq=5,
+    model_handler=None,
+    eval_freq=10,
+    num_eval_episodes=1,
+    rollout_saver=None,
+    save_train_rollout=False,
+    save_eval_rollout=True,
+    info_saver=None,
+    device=None,
+):
+    """PPO-clip with KL early stopping: the reference's main loop (ppo.py:230-377), argument for argument.
+    Under torch.distributed `envs` are THIS rank's environments and `num_steps_per_iter` counts this rank's steps;
+    rank 0 alone evaluates, logs and saves."""
+    dist, rank, world = _dist()
+    total_num_steps = start_num_steps
+    num_iterations = (max_num_steps - total_num_steps) // (num_steps_per_iter * world)
+    logging.info('Starting PPO')
+    for iteration in range(num_iterations):
+        logging.info(f'Iteration: {iteration}/{num_iterations - 1}, steps: {total_num_steps}')
+        train_container = PPOBufferContainer(size=envs.get_size(), gamma=gamma, lam=lam)
+        train_rollout = batch_rollout(ac=ac, envs=envs, buffer_container=train_container,
+                                      num_steps=num_steps_per_iter)
+        logging.info(f'Training rollout: return={train_rollout["return_mean"]:.3f} '
+                     f'({train_rollout["return_std"]:.1f}), episode length={train_rollout["episode_length_mean"]:.1f}')
+        train_buffer = train_container.merge()
+        if info_saver and rank == 0:
+            train_rollout['total_num_steps'] = total_num_steps
+            train_rollout.update(compute_buffer_stats(train_buffer))
+            info_saver.save(train_rollout, name='train')
+        if rollout_saver and save_train_rollout and rank == 0:
+            rollout_saver.save(train_buffer, num_steps=total_num_steps, info='train')
+
+        if dist is not None:
+            data = gather_rollout(train_buffer)
+        elif hasattr(ac, 'prepare_rollout') and next(ac.parameters()).device.type == 'cuda':
+            data = train_buffer.get_data(device=next(ac.parameters()).device)  # GAE + standardisation on the device
+        else:
+            data = train_buffer.get_data()
+        opt_info = train(ac=ac, optimizer=optimizer, data=data, mini_batch_size=mini_batch_size,
+                         clip_ratio=clip_ratio, vf_coef=vf_coef, entropy_coef=entropy_coef, target_kl=target_kl,
+                         gradient_clip=gradient_clip, max_num_steps=max_num_train_iters, device=device)
+        if info_saver and rank == 0:
+            opt_info['total_num_steps'] = total_num_steps
+            info_saver.save(opt_info, name='opt')
+        total_num_steps += num_steps_per_iter * world
+
+        if rank == 0 and ((iteration % eval_freq == 0) or (iteration == num_iterations - 1)):
+            eval_container = PPOBufferContainer(size=eval_envs.get_size(), gamma=gamma, lam=lam)
+            with torch.no_grad():
+                ac.training = False  # the reference flips the attribute directly (ppo.py:353,361)
+                eval_rollout = batch_rollout(ac, eval_envs, buffer_container=eval_container,
+                                             num_episodes=num_eval_episodes)
+                logging.info(f'Evaluation rollout: return={eval_rollout["return_mean"]:.3f} '
+                             f'({eval_rollout["return_std"]:.1f}), '
+                             f'episode length={eval_rollout["episode_length_mean"]:.1f}')
+                ac.training = True
+            eval_buffer = eval_container.merge()
+            if info_saver:
+                eval_rollout['total_num_steps'] = total_num_steps
+                eval_rollout.update(compute_buffer_stats(eval_buffer))
+                info_saver.save(eval_rollout, name='eval')
+            if rollout_saver and save_eval_rollout:
+                rollout_saver.save(eval_buffer, num_steps=total_num_steps, info='eval')
+        if rank == 0 and model_handler and ((iteration % save_freq == 0) or (iteration == num_iterations - 1)):
+            model_handler.save(ac, num_steps=total_num_steps)
+        if dist is not None:
+            dist.barrier()
+    logging.info('Finished PPO')

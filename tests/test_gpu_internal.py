@@ -196,10 +196,8 @@ def test_device_minibatch_equals_autograd_path(built_lib):
     loss.backward()
     want = ac.theta.grad.clone()
     ac.theta.grad = None
-    dev = ac.theta.device
-    f64 = lambda x: torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
-    stats = ac.ppo_minibatch(ac.make_batch(data['obs'], data['act']), f64(data['logp']), f64(data['adv']),
-                             f64(data['ret']), 0.2, 0.5, 0.01)
+    stats = ac.ppo_minibatch(ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret']),
+                             0.2, 0.5, 0.01)
     torch.cuda.synchronize()
     assert (ac.theta.grad - want).abs().max().item() < 1e-5 * want.abs().max().item()
     assert abs(stats[0].item() - info['policy_loss']) < 1e-6 * max(1.0, abs(info['policy_loss']))

@@ -148,3 +148,46 @@ def test_minibatches_in_flight_accumulate_like_sequential(built_lib):
     assert (ac.theta.grad - g_seq).abs().max().item() < 1e-5 * scale
     for a, b in zip(seq_stats, par_stats):
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_buffer_get_data_on_device_equals_host(built_lib):
+    """DynamicPPOBuffer.get_data(device=...) (mg_gae over all paths + mg_adv_normalize) == the reference's host form"""
+    from molgym_amd.buffer import PPOBufferContainer
+    rng = np.random.default_rng(0)
+    cont = PPOBufferContainer(size=5, gamma=0.99, lam=0.97)
+    d = make_batch(5, 7, [0, 9, 16], seed=0)
+    for t in range(9):
+        terminals = rng.random(5) < 0.3
+        cont.store(d['obs'], d['act'], rng.normal(size=5), d['obs'], terminals, rng.normal(size=5),
+                   rng.normal(-4, 1, size=5))
+    cont.finish_paths(rng.normal(size=5))
+    buf = cont.merge()
+    host, dev = buf.get_data(), buf.get_data(device='cuda:0')
+    assert dev['adv'].dtype == torch.float64 and dev['adv'].is_cuda
+    for k in ('adv', 'ret', 'logp'):
+        np.testing.assert_allclose(dev[k].cpu().numpy(), host[k], rtol=1e-11, atol=1e-13)
+    assert dev['obs'] is host['obs'] and np.array_equal(dev['act'], host['act'])
+
+
+def test_train_reports_the_reference_gradient_norm_and_clips(built_lib):
+    """train() takes norm / clip through mg_grad_norm_clip on the flat gradient: the reported norm is
+    util.compute_gradient_norm of the accumulated gradient, the step equals clip_grad_norm_ + optimizer step"""
+    from molgym_amd import ppo
+    ac, ref, cfg = make_pair('cfg2', seed=31)
+    data = make_batch(24, cfg['canvas_size'], cfg['zs'], seed=12)
+    before = ac.theta.detach().clone()
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+    g = ac.theta.grad.clone()
+    want_norm = g.norm().item()
+    p = torch.nn.Parameter(before.clone())
+    p.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_([p], 0.5)
+    opt_ref = torch.optim.SGD([p], lr=0.1)  # linear in the gradient (Adam's first step is g / |g|: noise where g ~ 0)
+    opt_ref.step()
+    ac.theta.grad = None
+    infos = ppo.train(ac, torch.optim.SGD(ac.parameters(), lr=0.1), data, mini_batch_size=24, clip_ratio=0.2,
+                      target_kl=1e9, vf_coef=0.5, entropy_coef=0.01, gradient_clip=0.5, max_num_steps=1)
+    assert abs(infos['grad_norm'] - want_norm) < 1e-4 * want_norm and want_norm > 0.5
+    assert (ac.theta.detach() - p.detach()).abs().max().item() < 1e-6
