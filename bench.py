@@ -5,9 +5,12 @@
 
 One step = one pass of the hot path over one synthetic mini-batch (molgym/ppo.py:124-131):
 ``step(obs, actions)`` -> float64 PPO loss -> backward into ``.grad`` (optimizer step excluded), with
-the parsed mini-batch already resident in HBM.  N > 1: one process per GPU (torchrun), every rank owns
-its own mini-batch of the same size (weak scaling), and the flat gradient is all-reduced over RCCL
-inside the timed region.  Rank 0 prints ONE JSON line.
+the parsed mini-batch already resident in HBM.  N > 1: one process per GPU -- launched by torchrun, or by this
+script itself when it is started plainly with --gpus N -- with the flat gradient all-reduced over RCCL inside the
+timed region; `--scaling weak` (default) gives every rank its own mini-batch of the configured size, `--scaling
+strong` shards ONE mini-batch of that size over the ranks.  Rank 0 prints ONE JSON line; `value` follows the contract
+(K steps between synchronisations, max over ranks), `config.median_ms_per_step` is the median over the same K steps
+from per-step HIP events.
 """
 import argparse
 import json
@@ -30,6 +33,9 @@ def parse_args():
     p.add_argument('--batch', type=int, default=None, help='override the mini-batch size per GPU')
     p.add_argument('--agent', default='covariant', choices=['covariant', 'internal'],
                    help="'internal' = SchNetAC (BASELINE configs[0]); single GPU, no roofline object")
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                   help='N > 1: weak = the configured mini-batch PER GPU; strong = ONE mini-batch of that size sharded '
+                        'over the GPUs (what ppo.train does with a fixed rollout)')
     p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
@@ -181,10 +187,22 @@ def main_internal(args):
     print(json.dumps(line))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def main():
     args = parse_args()
     if args.agent == 'internal':
         return main_internal(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: become the torchrun launch the driver would have made
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     wd = float(os.environ.get('BENCH_WATCHDOG', '0'))
     if wd > 0:  # dump all Python stacks and exit if the run wedges
         import faulthandler
@@ -196,8 +214,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -208,21 +225,30 @@ def main():
     if world > 1:
         dist.barrier()
 
-    from molgym_amd import _lib
     from molgym_amd.agents.covariant import CovariantAC
     from molgym_amd.spaces import ActionSpace, ObservationSpace
     from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch
     from tools.flops import forward_flops, step_flops
 
     cfg = dict(CONFIGS[args.config])
-    B = args.batch or cfg['batch']
+    B_glob = args.batch or cfg['batch']
+    if args.scaling == 'weak':   # every rank owns a mini-batch of the configured size
+        B = B_glob
+        data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=rank)
+    else:                        # strong: ONE mini-batch of the configured size, sharded over the ranks (ppo.train)
+        whole = make_batch(B_glob, cfg['canvas_size'], cfg['zs'], seed=0)
+        lo, hi = (rank * B_glob) // world, ((rank + 1) * B_glob) // world
+        B = hi - lo
+        if B == 0:
+            raise SystemExit(f'strong scaling: {B_glob} samples cannot feed {world} ranks')
+        data = {k: v[lo:hi] for k, v in whole.items()}
+    total_samples = world * B if args.scaling == 'weak' else B_glob
     torch.manual_seed(0)
     ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']),
                      bag_scale=cfg['bag_scale'], beta=cfg['beta'], device=dev, **MODEL_DEFAULTS)
-    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=rank)
     batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
     ac.theta.grad = torch.zeros_like(ac.theta)
-    inv_world = 1.0 / world
+    loss_scale = B / total_samples  # B_local / B_global: the all-reduced gradient is the global mini-batch mean
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
@@ -230,7 +256,7 @@ def main():
     def step():
         if streams is None:
             ac.theta.grad.zero_()
-            stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world)
+            stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
             if world > 1:
                 dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
             return stats
@@ -239,7 +265,7 @@ def main():
         k = counter[0] % len(streams)
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
-            return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=inv_world, slot=k)
+            return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, slot=k)
 
     def drain():
         if streams is not None:
@@ -251,13 +277,18 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
+    # per-step HIP events on the launch stream (no synchronisation inside the timed region): median step time
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         stats = step()
+        if streams is None:
+            marks[i + 1].record()
     drain()
     t_issued = time.perf_counter() - t0  # host time to enqueue the K steps (diagnostic: CPU-bound if ~= elapsed)
     torch.cuda.synchronize()
@@ -271,25 +302,32 @@ def main():
         elapsed = t.item()
     if not torch.isfinite(stats).all():
         raise SystemExit('non-finite loss statistics')
+    median_ms = None
+    if streams is None:
+        median_ms = float(np.median([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
+        value = total_samples * args.steps / elapsed
         natoms = [sum(1 for it in o[0] if cfg['zs'][it[0]] != 0) for o in data['obs']]
         f_dense = 3 * forward_flops(cfg['canvas_size'], len(cfg['zs']))  # SURVEY 8(d) per-sample figure
         f_ragged = step_flops(natoms, len(cfg['zs'])) / B
         # dominant kernel, timed live with HIP events on the launch stream
         from molgym_amd.profile import dominant_kernel_roofline
-        roof = dominant_kernel_roofline(ac, batch, natoms, cfg)
+        roof = dominant_kernel_roofline(ac, batch, natoms, cfg, args.config)
         line = {
             'metric': 'PPO mini-batch fwd+bwd samples/sec (covariant, canvas_size=%d)' % cfg['canvas_size'],
             'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.config}: covariant actor-critic, zs={cfg["zs"]}, canvas_size='
-                                   f'{cfg["canvas_size"]}, mini_batch={B} per GPU, beta={cfg["beta"]}, random-walk '
+                                   f'{cfg["canvas_size"]}, mini_batch={B} on this rank ({total_samples} over '
+                                   f'{world} GPU(s), {args.scaling} scaling), beta={cfg["beta"]}, random-walk '
                                    f'canvases with U{{0..N}} atoms, inputs resident in HBM',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'minibatches_in_flight': args.inflight,
+                       'global_batch': total_samples, 'parallelism': f'dp{world}',
+                       'minibatches_in_flight': args.inflight,
+                       'median_ms_per_step': median_ms,
+                       'samples_per_s_at_median': None if median_ms is None else total_samples / (median_ms * 1e-3),
                        'host_enqueue_ms_per_step': t_issued / args.steps * 1e3,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,

@@ -99,6 +99,11 @@ int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
                     const float* gout, float* grad_theta, void* stream);
 
+/* Input validation of the forward that just ran on `ws`: synchronises `stream`, then MG_EINVAL if the list build found
+ * real atoms that are not compacted to the front of their canvas, or cfg.TA / cfg.TE inconsistent with `charges`
+ * (the forward itself never synchronises, so it cannot report these).                                              */
+int mg_cov_check(const mg_cov_cfg* cfg, const void* ws, size_t ws_bytes, void* stream);
+
 /* ---- head outputs of the forward that just ran (what step()'s `dists` are built from, agent.py:224-286,325-331) ----
  * Packs, sample-major, out of the workspace:  focus logits [B][N] (0 beyond the sample's atoms) | natoms [B] (as f32) |
  * element logits [B][Z] | GMM head [B][2G] (mixture logits, then pre-tanh means) | conditioned orientation

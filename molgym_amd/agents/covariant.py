@@ -337,6 +337,8 @@ class CovariantAC(FlatThetaAgent):
                                                 _ptr(acts), _ptr(out), self._s()))
         self._last_ws = ws
         dists = self._dists(cfg, ws, d_bag)
+        with self._guard():  # this path synchronises for the actions anyway: surface the list build's error flags
+            _lib.check(_lib.lib().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
         host = acts.cpu().numpy()
         return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
                 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}

@@ -8,9 +8,10 @@
 #include "internal.inc"
 #include "dists.inc"
 
-static bool g_tables_ready = false;
+static bool g_tables_ready[MG_MAX_DEVICES];  // hipMemcpyToSymbol fills the CURRENT device's copy of a __constant__
 static int ensure_tables() {
-  if (g_tables_ready) return MG_OK;
+  const int dev = cur_device();
+  if (g_tables_ready[dev]) return MG_OK;
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_nblk), h_cg_nblk, sizeof(h_cg_nblk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_row_base), h_cg_row_base, sizeof(h_cg_row_base)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_row_start), h_cg_row_start, sizeof(h_cg_row_start)));
@@ -26,7 +27,7 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_pk), h_cgI_pk, sizeof(h_cgI_pk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_c), h_cgI_c, sizeof(h_cgI_c)));
   HIP_CHECK(hipDeviceSynchronize());
-  g_tables_ready = true;
+  g_tables_ready[dev] = true;
   return MG_OK;
 }
 
@@ -146,6 +147,10 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   rc = ws_build(c, P, ws, &w, nullptr);
   if (rc) return rc;
   rc = check_common(c, P, w, ws_bytes);
+  if (rc) return rc;
+  rc = check_device_of(theta, "theta");
+  if (rc) return rc;
+  rc = check_device_of(ws, "workspace");
   if (rc) return rc;
   rc = ensure_tables();
   if (rc) return rc;
@@ -379,6 +384,26 @@ extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const floa
   HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
   SampleCtx smp = {seed, mode};
   return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
+}
+
+// The list-build kernels flag inconsistent inputs in the workspace (encoder.inc: 1 = real atoms not compacted to the
+// front of a canvas, 2 = cfg.TA / cfg.TE differ from what `charges` holds).  Reading the flags costs a stream
+// synchronisation, so it is a separate call: the Python agent makes it wherever it synchronises anyway.
+extern "C" int mg_cov_check(const mg_cov_cfg* c, const void* ws, size_t ws_bytes, void* stream) {
+  PLayout P;
+  int rc = build_layout(c, &P);
+  if (rc) return rc;
+  WS w;
+  rc = ws_build(c, P, const_cast<void*>(ws), &w, nullptr);
+  if (rc) return rc;
+  if (ws_bytes < w.bytes) MG_FAIL(MG_ENOMEM, "workspace %zu bytes < required %zu", ws_bytes, w.bytes);
+  int flag = 0;
+  HIP_CHECK(hipMemcpyAsync(&flag, w.L.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (flag == 1) MG_FAIL(MG_EINVAL, "charges: the real atoms of a canvas must be compacted to the front (a padding slot precedes an atom)");
+  if (flag == 2) MG_FAIL(MG_EINVAL, "cfg.TA / cfg.TE do not match the atom counts in charges");
+  if (flag != 0) MG_FAIL(MG_EINVAL, "list build reported error %d", flag);
+  return MG_OK;
 }
 
 extern "C" int mg_cov_head_outputs(const mg_cov_cfg* c, const void* ws, size_t ws_bytes, float* out, void* stream) {

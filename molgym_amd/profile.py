@@ -1,5 +1,11 @@
-"""Live kernel timing for bench.py's roofline object: HIP events recorded by the library on the launch
-stream around its dominant kernels (mg_profile_enable / mg_profile_report, include/molgym_hip.h)."""
+"""Live kernel timing and roofline accounting for bench.py.
+
+Timing: HIP events recorded by the library on the launch stream around its dominant kernels
+(mg_profile_enable / mg_profile_report, include/molgym_hip.h).  Accounting: per kernel, the ALGORITHMIC flops of one
+launch in the dense-CG convention of SURVEY.md 8(d) / tools/flops.py (what `roofline.achieved` is computed from) and,
+beside it, the flops the kernel actually EXECUTES (it walks the 1392-term sparse Clebsch-Gordan table instead of the
+dense 25 x 25 x 25 projection), plus the algorithmic bytes it has to move.  HBM traffic per launch comes from the PMC
+summary of the SAME config (profiles/pmc_<config>.json, tools/pmc_summary.py) or is null -- never another config's."""
 import ctypes as C
 import json
 import os
@@ -9,7 +15,10 @@ import torch
 from . import _lib
 
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak == f32-input MFMA dense peak
+PEAK_HBM_GBPS = 8000.0   # HBM3E, ~8 TB/s
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CH, NLM, CG_NNZ = 10, 25, 1392
+M = [1, 3, 5, 7, 9]
 
 
 def kernel_spans(ac, batch, iters=20):
@@ -31,38 +40,87 @@ def kernel_spans(ac, batch, iters=20):
     return out
 
 
+def _dense_level_flops(n):
+    """forward flops of CG aggregate + CG power of ONE atom with n neighbours at a level >= 1 (dense projection)"""
+    f = 0
+    for l1 in range(5):
+        for l2 in range(5):
+            lo, hi = abs(l1 - l2), min(l1 + l2, 4)
+            proj = CH * M[l1] * M[l2] * sum(M[l] for l in range(lo, hi + 1)) * 4
+            f += n * CH * M[l1] * M[l2] * 8 + proj      # aggregate: kron over n neighbours + projection
+            f += CH * M[l1] * M[l2] * 6 + proj          # power
+    return f
+
+
+def _executed_level_flops(n):
+    """what the kernels execute for the same thing: 25 x 25 complex moments per channel and neighbour (8 flops each),
+    then the sparse table -- per term a real x complex multiply-add (4) for the aggregate and a complex product
+    plus the same (6 + 4) for the power"""
+    return n * CH * NLM * NLM * 8 + CH * CG_NNZ * (4 + 10)
+
+
+def catbuild_flops(natoms, adjoint):
+    """(dense-convention, executed) flops of one launch over all real atoms; the adjoint costs twice the forward"""
+    mul = 2 if adjoint else 1
+    return (mul * sum(_dense_level_flops(int(n)) * int(n) for n in natoms),
+            mul * sum(_executed_level_flops(int(n)) * int(n) for n in natoms))
+
+
 def catbuild_bwd_flops(natoms):
-    """Algorithmic flops of ONE k_catbuild_bwd launch (adjoint of CG aggregate + CG power + pass-through of one
-    level >= 1 over all real atoms): 2 x the forward count of tools/flops.py for that level."""
-    L, C_ = 4, 10
-    M = [2 * l + 1 for l in range(L + 1)]
-    tot = 0
-    for n in natoms:
-        n = int(n)
-        f = 0
-        for l1 in range(L + 1):
-            for l2 in range(L + 1):
-                lo, hi = abs(l1 - l2), min(l1 + l2, L)
-                proj = C_ * M[l1] * M[l2] * sum(M[l] for l in range(lo, hi + 1)) * 4
-                f += n * (n * C_ * M[l1] * M[l2] * 8 + proj)   # aggregate: kron over n neighbours + projection
-                f += n * (C_ * M[l1] * M[l2] * 6 + proj)        # power
-        tot += 2 * f
-    return tot
+    return catbuild_flops(natoms, True)[0]
 
 
-def dominant_kernel_roofline(ac, batch, natoms, cfg):
+def _algorithmic_bytes(name, natoms, num_zs):
+    """bytes one launch must move at least: its inputs read once + its outputs written once (f32)"""
+    ta = sum(int(n) for n in natoms)
+    te = sum(int(n) * int(n) for n in natoms)
+    reps = ta * NLM * 2 * CH * 4                      # one level of atom representations
+    edges = te * (5 * 2 * CH + 2 * NLM) * 4            # edge nets of the level + Y_lm
+    # concatenated CG channels [ag | in | sq] of one level: 62 KB per atom
+    cat = ta * sum(M[l] * 2 * CH * (2 * b + 1) for l, b in enumerate((5, 12, 16, 17, 15))) * 4
+    if name in ('k_catbuild', 'k_catbuild_bwd'):
+        return reps + edges + cat + (reps + edges if name.endswith('bwd') else 0)
+    if name in ('k_atom_fused', 'k_atom_fused_bwd'):   # concatenated channels never leave the chip
+        return 2 * reps + edges + (2 * reps + edges if name.endswith('bwd') else 0)
+    return None
+
+
+def _pmc_traffic(config, name):
+    path = os.path.join(ROOT, 'profiles', f'pmc_{config}.json')
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(name, {}).get('hbm_bytes_per_launch')
+
+
+def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
     spans = kernel_spans(ac, batch)
     per_step = {k: v[0] * v[1] for k, v in spans.items()}
-    name = 'k_catbuild_bwd'
+    cg = [k for k in spans if k.startswith(('k_catbuild', 'k_atom_fused'))]
+    name = max(cg or spans, key=lambda k: per_step[k])
     ms = spans[name][0]
-    flops = catbuild_bwd_flops(natoms)
-    achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
-    return {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'kernel': name,
-            'kernel_avg_ms': ms, 'launches_per_step': spans[name][1], 'algorithmic_flops_per_launch': flops,
-            'note': 'f32 VALU kernel; the f32-input MFMA dense peak equals the f32 vector peak on gfx950',
-            'span_ms_per_step': per_step}
+    dense, executed = catbuild_flops(natoms, name.endswith('bwd')) if name in cg else (None, None)
+    sec = ms * 1e-3
+    traffic = _pmc_traffic(config_name, name)
+    alg_bytes = _algorithmic_bytes(name, natoms, len(cfg['zs']))
+    out = {'bound': 'valu', 'unit': 'TFLOP/s', 'peak': PEAK_F32_TFLOPS, 'kernel': name, 'kernel_avg_ms': ms,
+           'launches_per_step': spans[name][1], 'traffic': traffic,
+           'note': 'f32 vector-ALU (VALU) kernel: the peak is the f32 vector peak (== the f32-input MFMA dense peak '
+                   'on gfx950); achieved / frac use the DENSE-CG algorithmic count of SURVEY 8(d), '
+                   'achieved_executed / frac_executed the flops the sparse-table kernel really executes',
+           'span_ms_per_step': per_step}
+    if dense is not None:
+        out.update(achieved=dense / sec / 1e12, frac=dense / sec / 1e12 / PEAK_F32_TFLOPS,
+                   achieved_dense=dense / sec / 1e12, achieved_executed=executed / sec / 1e12,
+                   frac_executed=executed / sec / 1e12 / PEAK_F32_TFLOPS, algorithmic_flops_per_launch=dense,
+                   executed_flops_per_launch=executed)
+    if alg_bytes is not None:
+        out['algorithmic_bytes_per_launch'] = alg_bytes
+        out['algorithmic_gbps'] = alg_bytes / sec / 1e9
+    if traffic is not None:  # second fraction of SURVEY 8(d): measured HBM GB/s against the 8 TB/s roof
+        out['hbm_gbps'] = traffic / sec / 1e9
+        out['hbm_frac'] = traffic / sec / 1e9 / PEAK_HBM_GBPS
+        if alg_bytes:
+            out['traffic_over_algorithmic'] = traffic / alg_bytes
+    else:
+        out['hbm_gbps'] = out['hbm_frac'] = None
+    return out

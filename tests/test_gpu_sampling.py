@@ -95,3 +95,79 @@ def test_so3_sampler_importance_identity(built_lib):
         lp_so3 = ac.workspace_view('parts', ccfg).view(6, len(obs))[3].double().cpu()
         est = torch.exp(-lp_so3).mean().item()
         assert abs(est / (4 * np.pi) - 1) < 0.08, (beta, est)
+
+
+@pytest.mark.parametrize('beta', [2.0, None])
+def test_evaluation_mode_draws_sit_at_the_top_of_their_distributions(built_lib, beta):
+    """ac.training = False (ppo.py:353): distance = GaussianMixtureModel.argmax (best of 128 draws, gmm.py:20-27),
+    orientation = best of 128 (ExpSO3Distribution) / 256 (SO3Distribution) accepted draws (spherical_dists.py:262,149).
+    Distributional check against the returned `dists`: the evaluation draws score far above typical samples."""
+    ac, ref, cfg = make_pair('cfg2', seed=35, beta=beta)
+    base = make_batch(64, cfg['canvas_size'], cfg['zs'], seed=16)
+    obs = [o for o in base['obs'] if any(it[0] != 0 for it in o[0])][:24]
+    torch.manual_seed(9)
+    with torch.no_grad():
+        ac.training = False
+        ev = ac.step(obs)
+        a = ev['a']
+        distance_dist, so3_dist = ev['dists'][2], ev['dists'][3]
+        # same conditioning (focus / element / distance fixed) -> the same orientation density for the comparison draws
+        torch.manual_seed(10)
+        d_samples = distance_dist.sample(torch.Size((512, )))                   # (512, B)
+        o_samples = so3_dist.sample(torch.Size((256, )))                        # (256, B, 3)
+        lp_d_eval, lp_d_samp = distance_dist.log_prob(a[:, 2]), distance_dist.log_prob(d_samples)
+        lp_o_eval, lp_o_samp = so3_dist.log_prob(a[:, 3:6]), so3_dist.log_prob(o_samples)
+    ac.training = True
+    # best-of-128 beats the 90th percentile of single draws for (nearly) every sample of the batch
+    q_d = torch.quantile(lp_d_samp, 0.90, dim=0)
+    q_o = torch.quantile(lp_o_samp, 0.90, dim=0)
+    assert (lp_d_eval >= q_d - 1e-4).float().mean().item() > 0.9
+    assert (lp_o_eval >= q_o - 1e-4).float().mean().item() > 0.9
+    # and never exceeds the mode by construction
+    grid = torch.tensor(__import__('molgym_amd.agents.dists', fromlist=['x']).fibonacci_grid(4096),
+                        dtype=torch.float32, device=a.device).unsqueeze(1)
+    assert (lp_o_eval <= so3_dist.log_prob(grid).max(dim=0).values + 5e-2).all()
+
+
+def test_list_build_errors_are_reported(built_lib):
+    """mg_cov_check: charges with a padding slot BEFORE an atom, or cfg.TA / TE inconsistent with charges, are
+    flagged by the list kernels and surfaced as MG_EINVAL (the forward itself never synchronises)"""
+    import ctypes as C
+    from molgym_amd import _lib
+    ac, ref, cfg = make_pair('cfg2', seed=36)
+    d = make_batch(6, cfg['canvas_size'], cfg['zs'], seed=17)
+    batch = ac.prepare_batch(d['obs'], d['act'])
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ac.forward_batch(batch)
+    ws = ac._last_ws
+    _lib.check(built_lib.mg_cov_check(C.byref(batch.cfg), P(ws), ws.numel(), S))  # consistent inputs: fine
+    bad = batch.charges.clone()
+    row = int((bad > 0).sum(dim=1).argmax())
+    bad[row, 0] = 0  # hole at the front of a populated canvas
+    batch.charges = bad
+    ac.forward_batch(batch)
+    assert built_lib.mg_cov_check(C.byref(batch.cfg), P(ws), ws.numel(), S) == -1
+    assert b'compacted' in built_lib.mg_last_error() or b'TA' in built_lib.mg_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_agents_on_two_devices_in_one_process(built_lib):
+    """per-device library state (CG tables, function attributes, side stream): an agent on cuda:1 while cuda:0 is the
+    current device gives the same numbers as on cuda:0"""
+    from molgym_amd.agents.covariant import CovariantAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS
+    cfg = CONFIGS['cfg2']
+    outs = []
+    d = make_batch(12, cfg['canvas_size'], cfg['zs'], seed=18)
+    for dev in ('cuda:0', 'cuda:1'):
+        torch.manual_seed(0)
+        ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']),
+                         bag_scale=cfg['bag_scale'], beta=cfg['beta'], device=dev, **MODEL_DEFAULTS)
+        torch.cuda.set_device(0)
+        out = ac.step(d['obs'], d['act'])
+        out['logp'].sum().backward()
+        outs.append((out['logp'].detach().cpu(), ac.theta.grad.cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-6)

@@ -1,0 +1,24 @@
+# usage (GPU box, through gpurun): bash tools/artifacts.sh <tag> [config] [steps]
+# contract bench line, kernel trace (+ per-kernel summary and one-step timeline) and the two PMC passes
+# (FETCH_SIZE / WRITE_SIZE, each in its own run with --kernel-trace only) of ONE config -> gpurun_out/<tag>/
+# (copy what should be judged into profiles/: <tag>_kernel_stats_<config>.csv, <tag>_timeline_<config>.txt,
+#  pmc_<config>.json -- bench.py reads the dominant kernel's HBM traffic from profiles/pmc_<config>.json)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+tag=${1:-r02}
+config=${2:-cfg2}
+steps=${3:-20}
+warm=3
+out=gpurun_out/$tag
+mkdir -p $out
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out -o fetch_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline > $out/fetch_$config.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out -o write_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline > $out/write_$config.log 2>&1
+python tools/pmc_summary.py $out/fetch_${config}_results.db $out/write_${config}_results.db $out/pmc_$config.json | head -8
+cp $out/pmc_$config.json profiles/pmc_$config.json
+BENCH_WATCHDOG=400 timeout -k 5 500 python bench.py --config $config --steps 50 --warmup 10 > $out/bench_$config.json 2> $out/bench_$config.err
+tail -1 $out/bench_$config.json | cut -c1-2500
+timeout -k 5 300 rocprofv3 --kernel-trace -d $out -o prof_$config -- python bench.py --config $config --steps $steps --warmup $warm --no-cpu-baseline > $out/bench_prof_$config.log 2>&1
+# launches in the trace: warm-up + timed steps + the 20 iterations of the live roofline leg
+python tools/rocpd_summary.py $out/prof_${config}_results.db $out/kernel_stats_$config.csv $((steps + warm + 20)) > /dev/null && head -14 $out/kernel_stats_$config.csv && tail -1 $out/kernel_stats_$config.csv
+python tools/rocpd_timeline.py $out/prof_${config}_results.db k_prep_weights > $out/timeline_$config.txt 2>&1
+rm -f $out/*_results.db
