@@ -26,6 +26,18 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_start), h_cgI_start, sizeof(h_cgI_start)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_pk), h_cgI_pk, sizeof(h_cgI_pk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_c), h_cgI_c, sizeof(h_cgI_c)));
+  {  // the term table the one-wave-per-(atom, channel) CG kernels walk: plain global memory (lane-varying reads)
+    unsigned int* pk = nullptr;
+    float* cf32 = nullptr;
+    unsigned short* rs = nullptr;
+    HIP_CHECK(hipMalloc(&pk, sizeof(h_cgS_pk)));
+    HIP_CHECK(hipMalloc(&cf32, sizeof(h_cg_t_c)));
+    HIP_CHECK(hipMalloc(&rs, sizeof(h_cg_row_start)));
+    HIP_CHECK(hipMemcpy(pk, h_cgS_pk, sizeof(h_cgS_pk), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(cf32, h_cg_t_c, sizeof(h_cg_t_c), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(rs, h_cg_row_start, sizeof(h_cg_row_start), hipMemcpyHostToDevice));
+    g_cgtab[dev] = {pk, cf32, rs};
+  }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
   return MG_OK;
@@ -123,7 +135,7 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scra
     const int n = (int)std::min((size_t)WPREP_MAX, all.size() - i0);
     for (int i = 0; i < n; ++i) {
       Lin* L = all[i0 + i];
-      a.w[i] = {theta + L->w_off, L->mf, L->mb, L->O, L->Q, L->ldf, L->ldb, L->cplx};
+      a.w[i] = {theta + L->w_off, L->mf, L->mb, L->O, L->Q, L->ldf, L->ldb, L->cplx, L->perm_n};
     }
     if (zero_scratch && i0 == 0) { a.zero_f = w.dwexp_all; a.zero_n = w.dwexp_floats; a.zero_i4 = w.L.err; }
     hipLaunchKernelGGL(k_prep_weights, dim3(8, n), dim3(256), 0, s, a);
@@ -249,8 +261,9 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       APtrs A;
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
-      ProfScope prof(s, "k_catbuild");
-      hipLaunchKernelGGL(k_catbuild, dim3(TA), dim3(256), CB_SMEM, s, w.L, A, E, w.Y, cd);
+      ProfScope prof(s, "k_catbuild_mfma");
+      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64), 0, s, w.L, A, E, w.Y, cd,
+                         g_cgtab[cur_device()], TA);
     }
     LAUNCH_CHECK();
     GemmG ga[5];
