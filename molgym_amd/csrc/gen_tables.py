@@ -111,6 +111,39 @@ def main():
                 r += 1
     assert len(term_pk) == len(terms)
 
+    # gather form of the adjoint (key (i1, i2) -> terms): position of the term's AGGREGATE entry inside one channel's
+    # slice of an atom's concatenated row block -- slice = for l, for m: [ag blocks | in | sq blocks] (2 nblk_l + 1
+    # complex per row) -- and the distance nblk_l + 1 from it to the POWER entry: off | (nblk_l + 1) << 16
+    slice_base, sb = [], 0
+    for l in range(MAXL + 1):
+        slice_base.append(sb)
+        sb += (2 * l + 1) * (2 * nblk[l] + 1)
+    assert sb == 775
+    g_pk = []
+    for key in range(625):
+        i1, i2 = key // 25, key % 25
+        l1, l2 = int(math.isqrt(i1)), int(math.isqrt(i2))
+        m = (i1 - l1 * l1 - l1) + (i2 - l2 * l2 - l2)
+        for q in range(t_start[key], t_start[key + 1]):
+            l, bp, _ = t_terms[q]
+            off = slice_base[l] + (m + l) * (2 * nblk[l] + 1) + bp
+            g_pk.append(off | ((nblk[l] + 1) << 16))
+
+    # work orders for the one-wave-per-(atom, channel) kernels: rows / keys sorted by DEcreasing term count, so that the
+    # 64 lanes of one pass have similar trip counts (the pass runs max-of-the-group predicated iterations)
+    def order(counts):
+        idx = sorted(range(len(counts)), key=lambda i: -counts[i])
+        gmax = [max(counts[i] for i in idx[g:g + 64]) for g in range(0, len(idx), 64)]
+        return idx, gmax
+    row_cnt = [row_start[r + 1] - row_start[r] for r in range(nrows)]
+    row_perm, row_gmax = order(row_cnt)
+    key_cnt = [t_start[k + 1] - t_start[k] for k in range(625)]
+    key_perm, key_gmax = order(key_cnt)
+    pairs = [(x, y) for x in range(25) for y in range(x, 25)]
+    pair_cnt = [key_cnt[x * 25 + y] + (key_cnt[y * 25 + x] if x != y else 0) for x, y in pairs]
+    pidx, pair_gmax = order(pair_cnt)
+    pair_perm = [pairs[i][0] * 25 + pairs[i][1] for i in pidx]
+
     out = []
     w = out.append
     w('// GENERATED by gen_tables.py -- do not edit.  Sparse real Clebsch-Gordan tables, maxl = 4.')
@@ -132,6 +165,18 @@ def main():
     w(f'static const float h_cgI_c[{len(inc_flat)}] = {{' + ', '.join(f'{e[2]:.9e}f' for e in inc_flat) + '};')
     w(f'static const unsigned short h_cgT_key[{len(terms)}] = {{' + ', '.join(map(str, t_keys)) + '};')
     w(f'static const unsigned int h_cgS_pk[{len(terms)}] = {{' + ', '.join(map(str, term_pk)) + '};')
+    w(f'static const unsigned int h_cgG_pk[{len(terms)}] = {{' + ', '.join(map(str, g_pk)) + '};')
+    w('static const int h_cg_slice_base[5] = {' + ', '.join(map(str, slice_base)) + '};')
+    w(f'static const unsigned short h_cg_row_perm[{nrows}] = {{' + ', '.join(map(str, row_perm)) + '};')
+    w('#define CG_ROW_GMAX {' + ', '.join(map(str, row_gmax)) + '}')
+    w(f'#define CG_ROW_NGRP {len(row_gmax)}')
+    w(f'static const unsigned short h_cg_key_perm[625] = {{' + ', '.join(map(str, key_perm)) + '};')
+    w('#define CG_KEY_GMAX {' + ', '.join(map(str, key_gmax)) + '}')
+    w(f'#define CG_KEY_NGRP {len(key_gmax)}')
+    w(f'#define CG_NPAIRS {len(pair_perm)}')
+    w(f'static const unsigned short h_cg_pair_perm[{len(pair_perm)}] = {{' + ', '.join(map(str, pair_perm)) + '};')
+    w('#define CG_PAIR_GMAX {' + ', '.join(map(str, pair_gmax)) + '}')
+    w(f'#define CG_PAIR_NGRP {len(pair_gmax)}')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cg_tables.inc')
     text = '\n'.join(out) + '\n'
     if os.path.exists(path) and open(path).read() == text:

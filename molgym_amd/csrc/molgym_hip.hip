@@ -27,16 +27,19 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_pk), h_cgI_pk, sizeof(h_cgI_pk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_c), h_cgI_c, sizeof(h_cgI_c)));
   {  // the term table the one-wave-per-(atom, channel) CG kernels walk: plain global memory (lane-varying reads)
-    unsigned int* pk = nullptr;
-    float* cf32 = nullptr;
-    unsigned short* rs = nullptr;
-    HIP_CHECK(hipMalloc(&pk, sizeof(h_cgS_pk)));
-    HIP_CHECK(hipMalloc(&cf32, sizeof(h_cg_t_c)));
-    HIP_CHECK(hipMalloc(&rs, sizeof(h_cg_row_start)));
-    HIP_CHECK(hipMemcpy(pk, h_cgS_pk, sizeof(h_cgS_pk), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(cf32, h_cg_t_c, sizeof(h_cg_t_c), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(rs, h_cg_row_start, sizeof(h_cg_row_start), hipMemcpyHostToDevice));
-    g_cgtab[dev] = {pk, cf32, rs};
+    auto up = [](const void* src, size_t bytes, void** dst) {
+      return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp;
+    if (!(up(h_cgS_pk, sizeof(h_cgS_pk), &pk) && up(h_cg_t_c, sizeof(h_cg_t_c), &cf32) &&
+          up(h_cg_row_start, sizeof(h_cg_row_start), &rs) && up(h_cgG_pk, sizeof(h_cgG_pk), &gpk) &&
+          up(h_cgT_c, sizeof(h_cgT_c), &gc) && up(h_cgT_start, sizeof(h_cgT_start), &gs) &&
+          up(h_cg_row_perm, sizeof(h_cg_row_perm), &rp) && up(h_cg_key_perm, sizeof(h_cg_key_perm), &kp) &&
+          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp)))
+      MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
+    g_cgtab[dev] = {(const unsigned*)pk, (const float*)cf32, (const unsigned short*)rs, (const unsigned*)gpk,
+                    (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned short*)kp,
+                    (const unsigned short*)pp};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
@@ -262,7 +265,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
       ProfScope prof(s, "k_catbuild_mfma");
-      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64), 0, s, w.L, A, E, w.Y, cd,
+      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64 * CGM_WAVES), 0, s, w.L, A, E, w.Y, cd,
                          g_cgtab[cur_device()], TA);
     }
     LAUNCH_CHECK();

@@ -1,0 +1,36 @@
+"""Debug tool (GPU box): phase timestamps (100 MHz ticks) inside k_catbuild_bwd_mfma for one wave.
+Usage: python tools/ts_cg.py <debug .so built with -DMG_TS> [config]"""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from molgym_amd import _lib
+
+_lib.LIB_PATH = sys.argv[1]
+from molgym_amd.agents.covariant import CovariantAC  # noqa: E402
+from molgym_amd.spaces import ActionSpace, ObservationSpace  # noqa: E402
+from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch  # noqa: E402
+
+name = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'
+cfg = CONFIGS[name]
+torch.manual_seed(0)
+ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']), bag_scale=cfg['bag_scale'],
+                 beta=cfg['beta'], device=torch.device('cuda'), **MODEL_DEFAULTS)
+data = make_batch(cfg['batch'], cfg['canvas_size'], cfg['zs'], seed=0)
+batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+lib = _lib.lib()
+lib.mg_debug_ts.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * 64)()
+for blk in (0, 8, 801):
+    lib.mg_debug_ts(buf, blk)
+    for _ in range(3):
+        ac.theta.grad = None
+        ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+    lib.mg_debug_ts(buf, blk)
+    ts = np.array(list(buf), dtype=np.int64)
+    names = ['load Ai', 'rebuild sq', 'power', 'rebuild ag', 'operands+stage', 'mfma', 'epilogues', 'dE+rest']
+    print('block', blk, {n: round((ts[33 + k] - ts[32 + k]) / 100.0, 2) for k, n in enumerate(names[:7])},
+          'total us', (ts[39] - ts[32]) / 100.0, '| fwd loads, mfma, cg:', [round((ts[41 + k] - ts[40 + k]) / 100.0, 2) for k in range(3)])
