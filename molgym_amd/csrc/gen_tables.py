@@ -144,6 +144,28 @@ def main():
     pidx, pair_gmax = order(pair_cnt)
     pair_perm = [pairs[i][0] * 25 + pairs[i][1] for i in pidx]
 
+    # forward projection, staged per part of the channel slice (parts: l <= 2, l = 3, l = 4): one word per output row,
+    # t0 | count << 11 | (slice position of the aggregate entry) << 15 | (nblk_l + 1) << 25, rows of a part sorted by
+    # decreasing term count and padded to groups of 64 lanes (padding: count 0, position 1023)
+    row_info = []
+    r = 0
+    for l in range(MAXL + 1):
+        for bp in range(nblk[l]):
+            for mi in range(2 * l + 1):
+                pos = slice_base[l] + mi * (2 * nblk[l] + 1) + bp
+                row_info.append((l, row_start[r], row_start[r + 1] - row_start[r], pos, nblk[l] + 1))
+                r += 1
+    rowS, rowS_gmax, rowS_part = [], [], []
+    for part, ls in enumerate(((0, 1, 2), (3, ), (4, ))):
+        rows = sorted((ri for ri in row_info if ri[0] in ls), key=lambda ri: -ri[2])
+        for g in range(0, len(rows), 64):
+            grp = rows[g:g + 64]
+            rowS_gmax.append(max(ri[2] for ri in grp))
+            rowS_part.append(part)
+            for ri in grp:
+                rowS.append(ri[1] | (ri[2] << 11) | (ri[3] << 15) | (ri[4] << 25))
+            rowS += [1023 << 15] * (64 - len(grp))
+
     out = []
     w = out.append
     w('// GENERATED by gen_tables.py -- do not edit.  Sparse real Clebsch-Gordan tables, maxl = 4.')
@@ -170,6 +192,10 @@ def main():
     w(f'static const unsigned short h_cg_row_perm[{nrows}] = {{' + ', '.join(map(str, row_perm)) + '};')
     w('#define CG_ROW_GMAX {' + ', '.join(map(str, row_gmax)) + '}')
     w(f'#define CG_ROW_NGRP {len(row_gmax)}')
+    w(f'static const unsigned int h_cg_rowS[{len(rowS)}] = {{' + ', '.join(map(str, rowS)) + '};')
+    w('#define CG_ROWS_GMAX {' + ', '.join(map(str, rowS_gmax)) + '}')
+    w('#define CG_ROWS_PART {' + ', '.join(map(str, rowS_part)) + '}')
+    w(f'#define CG_ROWS_NGRP {len(rowS_gmax)}')
     w(f'static const unsigned short h_cg_key_perm[625] = {{' + ', '.join(map(str, key_perm)) + '};')
     w('#define CG_KEY_GMAX {' + ', '.join(map(str, key_gmax)) + '}')
     w(f'#define CG_KEY_NGRP {len(key_gmax)}')

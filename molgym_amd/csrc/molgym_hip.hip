@@ -30,16 +30,16 @@ static int ensure_tables() {
     auto up = [](const void* src, size_t bytes, void** dst) {
       return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp;
+    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw;
     if (!(up(h_cgS_pk, sizeof(h_cgS_pk), &pk) && up(h_cg_t_c, sizeof(h_cg_t_c), &cf32) &&
           up(h_cg_row_start, sizeof(h_cg_row_start), &rs) && up(h_cgG_pk, sizeof(h_cgG_pk), &gpk) &&
           up(h_cgT_c, sizeof(h_cgT_c), &gc) && up(h_cgT_start, sizeof(h_cgT_start), &gs) &&
           up(h_cg_row_perm, sizeof(h_cg_row_perm), &rp) && up(h_cg_key_perm, sizeof(h_cg_key_perm), &kp) &&
-          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp)))
+          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp) && up(h_cg_rowS, sizeof(h_cg_rowS), &rw)))
       MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
     g_cgtab[dev] = {(const unsigned*)pk, (const float*)cf32, (const unsigned short*)rs, (const unsigned*)gpk,
-                    (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned short*)kp,
-                    (const unsigned short*)pp};
+                    (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned int*)rw,
+                    (const unsigned short*)kp, (const unsigned short*)pp};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
