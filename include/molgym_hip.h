@@ -99,6 +99,17 @@ int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,
                     const float* gout, float* grad_theta, void* stream);
 
+/* ---- persistent device canvases of the rollout (replaces the per-step re-parse of every observation,
+ * covariant/agent.py:165-197 + covariant/tools.py:8-49, between two steps of an episode) -----------------------------
+ * Appends the atom an action row places (to_action_space, agent.py:147-163) to each canvas IN PLACE:
+ *   new position = pos64[focus] + (double)(float)(distance * direction)   (origin on an empty canvas),
+ *   pos64 / pos32 / charges slot natoms <- it, bags[element] -= 1, natoms += 1   (skipped for a null element or a full canvas)
+ * actions [B][6] f32 (mg_cov_sample's actions_out); pos64 [B][N][3] f64 (the environment's own precision), pos32 its f32
+ * mirror (what mg_cov_sample / mg_cov_forward read), charges [B][N] i32, bags [B][Z] f32, natoms [B] i32;
+ * newpos [B][3] f64 out: the positions placed (what the host hands to the environments); zs_host: HOST array of Z ints. */
+int mg_canvas_append(int32_t B, int32_t N, int32_t Z, const int32_t* zs_host, const float* actions, double* pos64,
+                     float* pos32, int32_t* charges, float* bags, int32_t* natoms, double* newpos, void* stream);
+
 /* Input validation of the forward that just ran on `ws`: synchronises `stream`, then MG_EINVAL if the list build found
  * real atoms that are not compacted to the front of their canvas, or cfg.TA / cfg.TE inconsistent with `charges`
  * (the forward itself never synchronises, so it cannot report these).                                              */

@@ -42,6 +42,7 @@ SYMBOLS = {
     'mg_cov_forward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
     'mg_cov_sample': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, _P, C.c_size_t, _P, _P, _P]),
     'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
+    'mg_canvas_append': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P, _P]),
     'mg_cov_check': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P]),
     'mg_cov_head_outputs': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P, _P]),
     'mg_so3_density': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P, C.c_int32, _P, _P]),

@@ -343,6 +343,40 @@ class CovariantAC(FlatThetaAgent):
         return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
                 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
 
+    # -- persistent device canvases (rollouts): no per-step parse, the drawn atom is appended on the device -------------
+    def make_canvas(self, observations: List[ObservationType]) -> 'DeviceCanvas':
+        from .canvas import DeviceCanvas
+        return DeviceCanvas(self, observations)
+
+    def step_canvas(self, canvas: 'DeviceCanvas', commit: bool = True) -> Dict[str, Any]:
+        """step(observations) of the rollout on resident canvases: same sampling kernels, same return dict; with
+        `commit` the drawn atoms are then placed on the canvases in HBM (the host hands `actions` to the environments
+        and calls `canvas.sync` for the ones that were reset or changed in any other way)."""
+        B = canvas.E
+        natoms_before = canvas.natoms.copy()
+        cfg = self._make_cfg(B, natoms_before)
+        dev = self.theta.device
+        ws = self._workspace(cfg)
+        out = torch.empty(3, B, dtype=torch.float32, device=dev)
+        acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
+        seed = int(torch.randint(0, 2**62, (1, )).item())
+        mode = 1 if self.training else 2
+        with self._guard():
+            _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
+                                                _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws),
+                                                ws.numel(), _ptr(acts), _ptr(out), self._s()))
+        self._last_ws = ws
+        dists = self._dists(cfg, ws, canvas.bags.clone())
+        newpos = canvas.append(acts, commit)
+        host_a, host_p = acts.cpu().numpy(), newpos.cpu().numpy()  # the action rows and the positions they place
+        elements = np.rint(host_a[:, 1]).astype(np.int64)
+        if commit:
+            placed = (np.asarray(self.zs)[elements] != 0) & (natoms_before < cfg.N)
+            canvas.natoms = natoms_before + placed.astype(np.int32)
+            canvas.bags_host[np.nonzero(placed)[0], elements[placed]] -= 1
+        actions = [(int(e), (float(p[0]), float(p[1]), float(p[2]))) for e, p in zip(elements, host_p)]
+        return {'actions': actions, 'a': acts, 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
+
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""
         off, cnt = C.c_int64(), C.c_int64()

@@ -7,6 +7,7 @@
 #include "ppo.inc"
 #include "internal.inc"
 #include "dists.inc"
+#include "canvas.inc"
 
 static bool g_tables_ready[MG_MAX_DEVICES];  // hipMemcpyToSymbol fills the CURRENT device's copy of a __constant__
 static int ensure_tables() {
@@ -400,6 +401,18 @@ extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const floa
   HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
   SampleCtx smp = {seed, mode};
   return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
+}
+
+extern "C" int mg_canvas_append(int32_t B, int32_t N, int32_t Z, const int32_t* zs_host, const float* actions, double* pos64,
+                                float* pos32, int32_t* charges, float* bags, int32_t* natoms, double* newpos,
+                                void* stream) {
+  if (B < 1 || N < 1 || Z < 2 || Z > MG_MAX_Z) MG_FAIL(MG_EINVAL, "bad canvas shape B=%d N=%d Z=%d", B, N, Z);
+  CanvasZs zs;
+  for (int i = 0; i < 8; ++i) zs.z[i] = i < Z ? zs_host[i] : 0;
+  hipLaunchKernelGGL(k_canvas_append, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, B, N, Z, zs, actions, pos64,
+                     pos32, charges, bags, natoms, newpos);
+  LAUNCH_CHECK();
+  return MG_OK;
 }
 
 // The list-build kernels flag inconsistent inputs in the workspace (encoder.inc: 1 = real atoms not compacted to the

@@ -265,6 +265,10 @@ def batch_rollout(ac, envs, buffer_container: PPOBufferContainer, num_steps: Opt
     }
 
 
+def _use_canvas(ac) -> bool:
+    return hasattr(ac, 'make_canvas') and next(ac.parameters()).device.type == 'cuda'
+
+
 def _rollout_serial(ac, envs, container, num_steps, num_episodes):
     if num_steps is not None:
         assert num_steps % envs.get_size() == 0
@@ -277,15 +281,21 @@ def _rollout_serial(ac, envs, container, num_steps, num_episodes):
         num_episodes = np.inf
     counter = 0
     observations = envs.reset()
+    # agents with device-resident canvases (CovariantAC on the GPU): parse once, then only reset environments are uploaded
+    canvas = ac.make_canvas(observations) if _use_canvas(ac) else None
     while counter < num_iters and container.get_num_episodes() < num_episodes:
-        predictions = ac.step(observations)
+        predictions = ac.step_canvas(canvas) if canvas is not None else ac.step(observations)
         next_observations, rewards, terminals, _ = envs.step(predictions['actions'])
         a, v, logp = _host_predictions(predictions)
         container.store(observations=observations, actions=a, rewards=rewards, next_observations=next_observations,
                         terminals=terminals, values=v, logps=logp)
         observations = envs.reset_if_terminal(next_observations, terminals)  # a valid next observation either way
+        if canvas is not None:
+            stale = canvas.stale_rows(observations, terminals)
+            canvas.sync(stale, [observations[i] for i in stale])
         if counter == num_iters - 1:
-            _, v, _ = _host_predictions(ac.step(observations))
+            last = ac.step_canvas(canvas, commit=False) if canvas is not None else ac.step(observations)
+            _, v, _ = _host_predictions(last)
             container.finish_paths(v)  # bootstrap the cut-off paths; finished ones are untouched
         counter += 1
 

@@ -16,6 +16,7 @@ from . import _lib
 
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector peak == f32-input MFMA dense peak
 PEAK_HBM_GBPS = 8000.0   # HBM3E, ~8 TB/s
+CLOCK_HZ = 2.4e9
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CH, NLM, CG_NNZ = 10, 25, 1392
 M = [1, 3, 5, 7, 9]
@@ -70,6 +71,14 @@ def catbuild_bwd_flops(natoms):
     return catbuild_flops(natoms, True)[0]
 
 
+def mfma_issued_flops(natoms, adjoint):
+    """flops the matrix cores are ISSUED by one launch (16 x 16 x 4 tiles incl. zero padding): forward 32 MFMAs per
+    tile of 8 neighbours and (atom, channel); adjoint 54 per tile + 26 for the power block"""
+    per_tile = 54 if adjoint else 32
+    n_mfma = sum(CH * ((per_tile * -(-int(n) // 8)) + (26 if adjoint else 0)) * int(n) for n in natoms)
+    return n_mfma * 2 * 16 * 16 * 4
+
+
 def _algorithmic_bytes(name, natoms, num_zs):
     """bytes one launch must move at least: its inputs read once + its outputs written once (f32)"""
     ta = sum(int(n) for n in natoms)
@@ -78,10 +87,10 @@ def _algorithmic_bytes(name, natoms, num_zs):
     edges = te * (5 * 2 * CH + 2 * NLM) * 4            # edge nets of the level + Y_lm
     # concatenated CG channels [ag | in | sq] of one level: 62 KB per atom
     cat = ta * sum(M[l] * 2 * CH * (2 * b + 1) for l, b in enumerate((5, 12, 16, 17, 15))) * 4
-    if name in ('k_catbuild', 'k_catbuild_bwd'):
-        return reps + edges + cat + (reps + edges if name.endswith('bwd') else 0)
-    if name in ('k_atom_fused', 'k_atom_fused_bwd'):   # concatenated channels never leave the chip
-        return 2 * reps + edges + (2 * reps + edges if name.endswith('bwd') else 0)
+    if name == 'k_catbuild_mfma':        # reads the level's representations + edge nets + Y, writes the concatenated rows
+        return reps + edges + cat
+    if name == 'k_catbuild_bwd_mfma':    # reads their adjoint + the same inputs, writes edge / representation adjoints
+        return cat + reps + edges + reps + te * 5 * 2 * CH * 4
     return None
 
 
@@ -95,24 +104,28 @@ def _pmc_traffic(config, name):
 def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
     spans = kernel_spans(ac, batch)
     per_step = {k: v[0] * v[1] for k, v in spans.items()}
-    cg = [k for k in spans if k.startswith(('k_catbuild', 'k_atom_fused'))]
+    cg = [k for k in spans if k in ('k_catbuild_mfma', 'k_catbuild_bwd_mfma')]
     name = max(cg or spans, key=lambda k: per_step[k])
     ms = spans[name][0]
-    dense, executed = catbuild_flops(natoms, name.endswith('bwd')) if name in cg else (None, None)
+    dense, executed = catbuild_flops(natoms, 'bwd' in name) if name in cg else (None, None)
     sec = ms * 1e-3
     traffic = _pmc_traffic(config_name, name)
     alg_bytes = _algorithmic_bytes(name, natoms, len(cfg['zs']))
-    out = {'bound': 'valu', 'unit': 'TFLOP/s', 'peak': PEAK_F32_TFLOPS, 'kernel': name, 'kernel_avg_ms': ms,
+    out = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_TFLOPS, 'kernel': name, 'kernel_avg_ms': ms,
            'launches_per_step': spans[name][1], 'traffic': traffic,
-           'note': 'f32 vector-ALU (VALU) kernel: the peak is the f32 vector peak (== the f32-input MFMA dense peak '
-                   'on gfx950); achieved / frac use the DENSE-CG algorithmic count of SURVEY 8(d), '
-                   'achieved_executed / frac_executed the flops the sparse-table kernel really executes',
+           'note': 'f32 kernel: neighbour contractions on v_mfma_f32_16x16x4_f32 (dense f32 MFMA peak 157.3 TFLOP/s == '
+                   'the f32 vector peak on gfx950), sparse CG projection on the vector ALUs; achieved / frac use the '
+                   'DENSE-CG algorithmic count of SURVEY 8(d), achieved_executed / frac_executed the useful flops of '
+                   'the sparse-table algorithm the kernel implements (MFMA tile padding not counted)',
            'span_ms_per_step': per_step}
     if dense is not None:
         out.update(achieved=dense / sec / 1e12, frac=dense / sec / 1e12 / PEAK_F32_TFLOPS,
                    achieved_dense=dense / sec / 1e12, achieved_executed=executed / sec / 1e12,
                    frac_executed=executed / sec / 1e12 / PEAK_F32_TFLOPS, algorithmic_flops_per_launch=dense,
-                   executed_flops_per_launch=executed)
+                   executed_flops_per_launch=executed,
+                   mfma_issued_tflops=mfma_issued_flops(natoms, 'bwd' in name) / sec / 1e12,
+                   # matrix-core utilisation: issued v_mfma_f32_16x16x4_f32 x 32 cycles per SIMD over the 1024 SIMDs
+                   mfma_pipe_util=mfma_issued_flops(natoms, 'bwd' in name) / 2048 * 32 / (sec * CLOCK_HZ * 1024))
     if alg_bytes is not None:
         out['algorithmic_bytes_per_launch'] = alg_bytes
         out['algorithmic_gbps'] = alg_bytes / sec / 1e9

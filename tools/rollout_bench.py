@@ -35,6 +35,15 @@ def main():
     ac.training = True
     dt = timeit(lambda: ac.step(obs))
     print(f'covariant step(obs) B={B}: {dt * 1e3:.3f} ms -> {B / dt:.0f} samples/s (host parse + D2H of the actions included)')
+    canvas = ac.make_canvas(obs)
+    dt = timeit(lambda: ac.step_canvas(canvas, commit=False))
+    print(f'covariant step_canvas B={B}: {dt * 1e3:.3f} ms -> {B / dt:.0f} samples/s (device-resident canvases: no parse; '
+          f'D2H of the actions and placed positions included)')
+    t0 = time.perf_counter()
+    for _ in range(20):
+        canvas.sync(list(range(0, B, 7)), [obs[i] for i in range(0, B, 7)])
+    torch.cuda.synchronize()
+    print(f'  canvas.sync of {len(range(0, B, 7))} reset environments: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
     ia = SchNetAC(osp, asp, (0.8, 1.8), 128, device='cuda:0')
     ia.training = True
     dt = timeit(lambda: ia.step(obs), n=5, warm=1)
