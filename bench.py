@@ -40,6 +40,9 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
+    p.add_argument('--force-dist', action='store_true',
+                   help='exercise the multi-GPU code path at N = 1 too: re-exec under torchrun, RCCL process group, '
+                        'gradient all-reduce in the step (a 1-GPU box can then check what the 8-GPU run will execute)')
     return p.parse_args()
 
 
@@ -198,7 +201,7 @@ def main():
     args = parse_args()
     if args.agent == 'internal':
         return main_internal(args)
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` on its own: become the torchrun launch the driver would have made
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
                '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -217,12 +220,13 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
     if rank == 0 and not args.no_build:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from molgym_amd.agents.covariant import CovariantAC
@@ -257,7 +261,7 @@ def main():
         if streams is None:
             ac.theta.grad.zero_()
             stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
             return stats
         # epoch semantics of ppo.train: gradients of independent mini-batches accumulate; they are issued
@@ -271,7 +275,7 @@ def main():
         if streams is not None:
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(ac.theta.grad)
 
     for _ in range(args.warmup):
@@ -280,7 +284,7 @@ def main():
     # per-step HIP events on the launch stream (no synchronisation inside the timed region): median step time
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -292,11 +296,11 @@ def main():
     drain()
     t_issued = time.perf_counter() - t0  # host time to enqueue the K steps (diagnostic: CPU-bound if ~= elapsed)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -324,7 +328,7 @@ def main():
                                    f'{cfg["canvas_size"]}, mini_batch={B} on this rank ({total_samples} over '
                                    f'{world} GPU(s), {args.scaling} scaling), beta={cfg["beta"]}, random-walk '
                                    f'canvases with U{{0..N}} atoms, inputs resident in HBM',
-                       'global_batch': total_samples, 'parallelism': f'dp{world}',
+                       'global_batch': total_samples, 'parallelism': f'dp{world}' + (' (RCCL path forced)' if args.force_dist and world == 1 else ''),
                        'minibatches_in_flight': args.inflight,
                        'median_ms_per_step': median_ms,
                        'samples_per_s_at_median': None if median_ms is None else total_samples / (median_ms * 1e-3),
@@ -340,7 +344,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
