@@ -36,13 +36,15 @@ class FakeMolEnv:
             return self._obs(), 0.0, True, {}
         if self.bag[element] <= 0 or any(np.linalg.norm(np.subtract(position, p)) < 0.6 for _, p in self.atoms):
             return self._obs(), self.min_reward, True, {}
+        t0 = time.perf_counter()  # CLOCK_MONOTONIC: comparable across the worker processes
         burn(self.work)
+        t1 = time.perf_counter()
         digest = hashlib.sha256(repr((self.atoms, element, tuple(np.round(position, 6)))).encode()).digest()
         reward = (int.from_bytes(digest[:4], 'little') / 2**32 - 0.3)  # deterministic pseudo energy gain
         self.atoms.append((element, tuple(float(x) for x in position)))
         self.bag[element] -= 1
         done = len(self.atoms) == self.N or sum(self.bag) == 0
-        return self._obs(), reward, done, {'elapsed_time': self.work}
+        return self._obs(), reward, done, {'elapsed_time': self.work, 'span': (t0, t1)}
 
 
 class FakeAC(torch.nn.Module):
@@ -53,9 +55,12 @@ class FakeAC(torch.nn.Module):
         self.zs, self.gpu_seconds = list(zs), gpu_seconds
         self.w = torch.nn.Parameter(torch.zeros(1))
         self.training = True
+        self.spans = []  # (start, end) of every policy evaluation
 
     def step(self, observations, actions=None):
+        t0 = time.perf_counter()
         time.sleep(self.gpu_seconds)  # a device-side policy evaluation: the host thread is idle meanwhile
+        self.spans.append((t0, time.perf_counter()))
         rows, acts = [], []
         for canvas, bag in observations:
             rng = np.random.default_rng(int.from_bytes(hashlib.sha256(repr((canvas, bag)).encode()).digest()[:8], 'little'))
