@@ -20,8 +20,10 @@
 __device__ unsigned long long g_ts[64];
 __device__ int g_ts_block;
 #define TS(i) do { if (blockIdx.x == g_ts_block && blockIdx.y == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
+#define TSY(i) do { if (blockIdx.x == g_ts_block && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
 #else
 #define TS(i) do { } while (0)
+#define TSY(i) do { } while (0)
 #endif
 
 struct cf {  // complex float

@@ -211,12 +211,30 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     // the radial Linears of all three levels depend on the geometry only: side stream, beside the input Linear
     // and the first DotMatrix (they fill the radial columns of cat_e[k]; joined before the first edge cat-mix)
     hipStream_t ss = side_fork(s);
-    GemmG gr[15];  // one launch for the 3 x 5 radial Linears
-    for (int k = 0; k < 3; ++k)
-      for (int l = 0; l < 5; ++l)
-        gr[5 * k + l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE,
-                                  0, nullptr);
-    RC(launch_gemm(ss, gr, 15));
+    if (!w.shared_dot) {
+      GemmG gr[15];  // one launch for the 3 x 5 radial Linears
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 5; ++l)
+          gr[5 * k + l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE,
+                                    0, nullptr);
+      RC(launch_gemm(ss, gr, 15));
+    } else {
+    SxArgs ra;  // one launch for the 3 x 5 radial Linears: the five of a level share its radial basis
+    memset(&ra, 0, sizeof(ra));
+    ra.rows = TE;
+    for (int k = 0; k < 3; ++k) {
+      SxSet& S = ra.set[k];
+      S.Xs = w.phi[k]; S.ldxs = NRADF; S.Rs = NRADF; S.ngroups = 5;
+      for (int l = 0; l < 5; ++l) {
+        const Lin& R = w.rad[k][l];
+        SxG& g = S.g[l];
+        g.Ms = R.mf; g.ldm = R.ldf; g.N = R.N;
+        g.bias = R.b_off >= 0 ? theta + R.b_off : nullptr;
+        g.Y = w.cat_e[k][l] + w.rcol[k][l]; g.ldy = w.ld_e[k][l];
+      }
+    }
+    RC(launch_sx(ss, ra, 3));
+    }
   }
   if (TA > 0) {
     stream_wait(s, weights_ready);
@@ -236,20 +254,49 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
       DotDst d;
-      for (int l = 0; l < 5; ++l) { d.p[l] = w.cat_e[k][l]; d.ld[l] = w.ld_e[k][l]; }
-      d.col = w.dcol[k];
-      d.nparts = 5;
+      if (w.shared_dot) {
+        for (int l = 0; l < 5; ++l) { d.p[l] = w.dotbuf[k]; d.ld[l] = 10 * CH; }
+        d.col = 0;
+        d.nparts = 1;
+      } else {
+        for (int l = 0; l < 5; ++l) { d.p[l] = w.cat_e[k][l]; d.ld[l] = w.ld_e[k][l]; }
+        d.col = w.dcol[k];
+        d.nparts = 5;
+      }
       hipLaunchKernelGGL(k_dot, dim3((TE * 50 + 255) / 256), dim3(256), 0, s, TE, w.L, A, d);
     }
     LAUNCH_CHECK();
-    GemmG ge[5];
-    for (int l = 0; l < 5; ++l) {
-      float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
-      const int ldE = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
-      ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
-    }
     if (k == 0) side_join(s);  // radial columns of every level are in place
-    RC(launch_gemm(s, ge, 5));  // (level 0: l = 0 has a different reduction width; the MFMA row form takes both)
+    if (k == 0 || !w.shared_dot) {
+      GemmG ge[5];
+      for (int l = 0; l < 5; ++l) {
+        float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+        const int ldE = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+        ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
+      }
+      RC(launch_gemm(s, ge, 5));  // (level 0: l = 0 has a different reduction width; the MFMA row form takes both)
+    } else {
+      // weight rows of the edge mix: [previous edge net (2 CH) | dot block (10 CH) | radial (2 CH)]
+      SxArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.rows = TE;
+      ea.rowscale = w.em;
+      SxSet& S = ea.set[0];
+      S.Xs = w.dotbuf[k]; S.ldxs = 10 * CH; S.Rs = 10 * CH; S.ngroups = 5;
+      for (int l = 0; l < 5; ++l) {
+        const Lin& E = w.edge[k][l];
+        SxG& g = S.g[l];
+        g.ldm = E.ldf; g.N = E.N;
+        g.Mp0 = E.mf; g.Rp0 = 2 * CH;
+        g.Ms = E.mf + (size_t)(2 * CH) * E.ldf;
+        g.Mp1 = E.mf + (size_t)(12 * CH) * E.ldf; g.Rp1 = 2 * CH;
+        g.Xp = w.cat_e[k][l]; g.ldxp = w.ld_e[k][l];
+        g.bias = E.b_off >= 0 ? theta + E.b_off : nullptr;
+        g.Y = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+        g.ldy = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+      }
+      RC(launch_sx(s, ea, 1));
+    }
     // --- atom level k (CG aggregate, CG power, cat-mix) ---
     EPtrs E;
     for (int l = 0; l < 5; ++l) {

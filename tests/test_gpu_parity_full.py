@@ -82,3 +82,23 @@ def test_sf6_full_minibatch_140_vs_oracle(built_lib):
     from oracle.covariant_ref import parse_observations
     natoms = parse_observations(data['obs'], cfg['zs'], cfg['canvas_size'], torch.float64)['num_atoms'].numpy()
     assert int(ac.workspace_view_int('err', ac._make_cfg(140, natoms))[0]) == 0
+
+
+@pytest.mark.gpu
+def test_shared_dot_block_layout_vs_oracle(built_lib):
+    """With many edges (>= 16384) the edge levels keep ONE copy of the DotMatrix block and run the shared-input MFMA
+    kernels (gemm.inc: k_gemm_mfma_sx / k_gemm_mfma_pk, segmented weight-gradient inputs).  The oracle cannot reach that
+    size in seconds, so the same kernels are forced on the small oracle cases (MG_SX_MIN_ROWS=1, read once per process:
+    hence the child interpreter)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MG_SX_MIN_ROWS='1')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
+                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
+                        os.path.join(here, 'test_gpu_forward.py'),
+                        '-k', 'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or encoder_stages'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'deselected' in r.stdout
