@@ -228,7 +228,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) {
         const Lin& R = w.rad[k][l];
         SxG& g = S.g[l];
-        g.Ms = R.mf; g.ldm = R.ldf; g.N = R.N;
+        g.M = R.mf; g.row_s = 0; g.ldm = R.ldf; g.N = R.N;
         g.bias = R.b_off >= 0 ? theta + R.b_off : nullptr;
         g.Y = w.cat_e[k][l] + w.rcol[k][l]; g.ldy = w.ld_e[k][l];
       }
@@ -286,10 +286,10 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) {
         const Lin& E = w.edge[k][l];
         SxG& g = S.g[l];
-        g.ldm = E.ldf; g.N = E.N;
-        g.Mp0 = E.mf; g.Rp0 = 2 * CH;
-        g.Ms = E.mf + (size_t)(2 * CH) * E.ldf;
-        g.Mp1 = E.mf + (size_t)(12 * CH) * E.ldf; g.Rp1 = 2 * CH;
+        g.M = E.mf; g.ldm = E.ldf; g.N = E.N;
+        g.row_p0 = 0; g.Rp0 = 2 * CH;
+        g.row_s = 2 * CH;
+        g.row_p1 = 12 * CH; g.Rp1 = 2 * CH;
         g.Xp = w.cat_e[k][l]; g.ldxp = w.ld_e[k][l];
         g.bias = E.b_off >= 0 ? theta + E.b_off : nullptr;
         g.Y = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
