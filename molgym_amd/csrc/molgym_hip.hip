@@ -126,7 +126,11 @@ static int check_common(const mg_cov_cfg* c, const PLayout& P, const WS& w, size
   return MG_OK;
 }
 
-static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scratch = false) {
+struct ListsJob {  // the small list build riding on the weight-preparation launch (k_prep_lists)
+  const int32_t* charges;
+  int B, N, TA, TE;
+};
+static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scratch = false, const ListsJob* lj = nullptr) {
   std::vector<Lin*> all;
   for (int k = 0; k < 3; ++k)
     for (int l = 0; l < 5; ++l) { all.push_back(&w.rad[k][l]); all.push_back(&w.edge[k][l]); all.push_back(&w.atom[k][l]); }
@@ -142,7 +146,12 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scra
       a.w[i] = {theta + L->w_off, L->mf, L->mb, L->O, L->Q, L->ldf, L->ldb, L->cplx, L->perm_n};
     }
     if (zero_scratch && i0 == 0) { a.zero_f = w.dwexp_all; a.zero_n = w.dwexp_floats; a.zero_i4 = w.L.err; }
-    hipLaunchKernelGGL(k_prep_weights, dim3(8, n), dim3(256), 0, s, a);
+    if (lj && i0 == 0) {
+      a.zero_i4 = nullptr;  // cleared by the list row itself, before it may raise them
+      hipLaunchKernelGGL(k_prep_lists, dim3(2, n + 1), dim3(1024), 0, s, a, n, lj->charges, lj->B, lj->N, lj->TA, lj->TE, w.L);
+    } else {
+      hipLaunchKernelGGL(k_prep_weights, dim3(8, n), dim3(256), 0, s, a);
+    }
     LAUNCH_CHECK();
   }
   return MG_OK;
@@ -177,10 +186,14 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   // the derived weight matrices (and the zero of the expanded weight-gradient scratch the backward accumulates
   // into) do not depend on the batch: side stream, beside the list / geometry kernels
   hipEvent_t weights_ready = nullptr;
+  bool lists_done = false;
   {
     hipStream_t ss = side_fork(s);
     if (ss == s) {
-      RC(prep_weights(s, theta, w, true));  // one launch: derived weights, zero of dwexp and of the error flags
+      // one launch: derived weights, zero of dwexp and of the error flags -- and, on small mini-batches, the list build
+      const ListsJob lj = {charges, B, N, TA, TE};
+      lists_done = (B <= MG_LISTS_SMALL_B && N <= 16);
+      RC(prep_weights(s, theta, w, true, lists_done ? &lj : nullptr));
     } else {
       RC(prep_weights(ss, theta, w));
       HIP_CHECK(hipMemsetAsync(w.dwexp_all, 0, w.dwexp_floats * sizeof(float), ss));
@@ -188,7 +201,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       HIP_CHECK(hipMemsetAsync(w.L.err, 0, 4 * sizeof(int), s));
     }
   }
-  if (B <= MG_LISTS_SMALL_B && N <= 16) {
+  if (lists_done) {
+  } else if (B <= MG_LISTS_SMALL_B && N <= 16) {
     hipLaunchKernelGGL(k_lists_small, dim3(1), dim3(1024), 0, s, charges, B, N, TA, TE, w.L);
     LAUNCH_CHECK();
   } else {
@@ -201,10 +215,20 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   ZsArr zs;
   for (int i = 0; i < 8; ++i) { zs.z[i] = i < Z ? c->zs[i] : -1; if (i < Z && c->zs[i] > maxz) maxz = c->zs[i]; }
   const float soft_rad = fmaxf(1e-3f, fminf(c->max_distance, 2.1f)), soft_width = 0.2f;
+  InLinArgs ia = {TA, N, Z, zs, (float)maxz, c->bag_scale, charges, bags, w.lin_in.mf, w.lin_in.ldf,
+                  w.lin_in.b_off >= 0 ? theta + w.lin_in.b_off : nullptr, 2 * CH, w.scal, w.A0};
+  const unsigned n_in = (unsigned)((TA * 2 * CH + 255) / 256);
+  bool input_done = false;
   if (TE > 0) {
-    GeomOut go = {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}};
-    hipLaunchKernelGGL(k_geom, dim3((4 * TE + 255) / 256), dim3(256), 0, s, TE, N, pos, w.L, theta, (int)P.rad_scales[0],
-                       (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]), soft_rad, soft_width, go);
+    GeomArgs ga = {TE, N, pos, theta, (int)P.rad_scales[0], (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]),
+                   soft_rad, soft_width, {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}}};
+    const unsigned n_geom = (unsigned)((4 * TE + 255) / 256);
+    if (!weights_ready && TA > 0 && !side_active()) {  // one stream: the input Linear rides on the geometry launch
+      hipLaunchKernelGGL(k_geom_input, dim3(n_geom + n_in), dim3(256), 0, s, ga, ia, w.L, (int)n_geom);
+      input_done = true;
+    } else {
+      hipLaunchKernelGGL(k_geom, dim3(n_geom), dim3(256), 0, s, ga, w.L);
+    }
     LAUNCH_CHECK();
   }
   if (TE > 0 && TA > 0) {
@@ -236,12 +260,10 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     RC(launch_sx(ss, ra, 3));
     }
   }
-  if (TA > 0) {
+  if (TA > 0 && !input_done) {
     stream_wait(s, weights_ready);
     weights_ready = nullptr;
-    hipLaunchKernelGGL(k_input_linear, dim3((TA * 2 * CH + 255) / 256), dim3(256), 0, s, TA, N, Z, zs, (float)maxz,
-                       c->bag_scale, charges, bags, w.L, w.lin_in.mf, w.lin_in.ldf,
-                       w.lin_in.b_off >= 0 ? theta + w.lin_in.b_off : nullptr, 2 * CH, w.scal, w.A0);
+    hipLaunchKernelGGL(k_input_linear, dim3(n_in), dim3(256), 0, s, ia, w.L);
     LAUNCH_CHECK();
   }
   for (int k = 0; k < 3 && TA > 0; ++k) {
