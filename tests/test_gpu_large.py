@@ -106,8 +106,10 @@ def test_kernel_families_agree_at_full_size(built_lib, tmp_path, name):
     """MFMA GEMM forms + side stream (default) against the VALU forms on one stream, same inputs and weights: the
     predictions, the loss statistics and the whole gradient vector"""
     a = _run_worker(name, {}, str(tmp_path / 'a.npz'))
-    b = _run_worker(name, {'MG_MFMA': '0', 'MG_MFMA_DX': '0', 'MG_MFMA_DW': '0', 'MG_NO_SIDE_STREAM': '1'},
-                    str(tmp_path / 'b.npz'))
+    # (MG_SX_MIN_ROWS=0: the plain edge-level layout -- the dot block copied into every degree's rows -- which is the one
+    # the lane-per-row forms can read; the default run uses the shared block and the shared-input MFMA kernels)
+    b = _run_worker(name, {'MG_MFMA': '0', 'MG_MFMA_DX': '0', 'MG_MFMA_DW': '0', 'MG_NO_SIDE_STREAM': '1',
+                           'MG_SX_MIN_ROWS': '0'}, str(tmp_path / 'b.npz'))
     assert np.isfinite(a['grad']).all() and np.isfinite(a['pred']).all()
     assert np.abs(a['pred'] - b['pred']).max() < 1e-5 * max(1.0, np.abs(b['pred']).max())
     assert np.abs(a['stats'] - b['stats']).max() < 1e-5 * max(1.0, np.abs(b['stats']).max())
