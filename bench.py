@@ -38,6 +38,7 @@ def parse_args():
                         'over the GPUs (what ppo.train does with a fixed rollout)')
     p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-epoch-overlap', action='store_true', help='skip the three-in-flight leg (profiling runs)')
     p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
     p.add_argument('--force-dist', action='store_true',
@@ -311,7 +312,7 @@ def main():
     # mini-batches accumulate into it (molgym/ppo.py:117-131), so they are independent given theta.  Reported beside the
     # headline (which stays strictly one mini-batch at a time), never instead of it.
     epoch_leg = None
-    if streams is None and not use_dist and world == 1 and B <= 512:
+    if streams is None and not use_dist and world == 1 and B <= 512 and not args.no_epoch_overlap:
         ep_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
         def ep_step(i):
