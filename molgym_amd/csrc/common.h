@@ -111,3 +111,22 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Per-degree pointers / strides arrive as small arrays inside kernel arguments; indexing those with a LANE-VARYING l
+// makes the compiler fetch them from the kernarg segment per lane (a dependent global load in front of every data
+// load).  They are read once into scalars and chosen with compare/select chains instead.
+struct Sel5P { const float *p0, *p1, *p2, *p3, *p4; };
+struct Sel5M { float *p0, *p1, *p2, *p3, *p4; };
+struct Sel5I { int v0, v1, v2, v3, v4; };
+__device__ __forceinline__ const float* sel5(const Sel5P& s, int l) {
+  return l == 0 ? s.p0 : l == 1 ? s.p1 : l == 2 ? s.p2 : l == 3 ? s.p3 : s.p4;
+}
+__device__ __forceinline__ float* sel5(const Sel5M& s, int l) {
+  return l == 0 ? s.p0 : l == 1 ? s.p1 : l == 2 ? s.p2 : l == 3 ? s.p3 : s.p4;
+}
+__device__ __forceinline__ int sel5(const Sel5I& s, int l) {
+  return l == 0 ? s.v0 : l == 1 ? s.v1 : l == 2 ? s.v2 : l == 3 ? s.v3 : s.v4;
+}
+#define SEL5P(arr) Sel5P{(arr)[0], (arr)[1], (arr)[2], (arr)[3], (arr)[4]}
+#define SEL5M(arr) Sel5M{(arr)[0], (arr)[1], (arr)[2], (arr)[3], (arr)[4]}
+#define SEL5I(arr) Sel5I{(arr)[0], (arr)[1], (arr)[2], (arr)[3], (arr)[4]}
