@@ -357,7 +357,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     HeadBuf HB;
     make_head_args(c, P, w, theta, &HD, &HW, &HB);
     ProfScope prof(s, "k_heads_fwd");
-    hipLaunchKernelGGL(k_heads_fwd, dim3(B, 2), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, A3, actions,
+    hipLaunchKernelGGL(k_heads_fwd, dim3(B, 3), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, A3, actions,
                        bags, leb, out);
     LAUNCH_CHECK();
     return MG_OK;
