@@ -74,3 +74,32 @@ def test_grads_accumulate_over_minibatches(built_lib):
         gw = want[name].grad.reshape(-1)
         scale = max(gw.abs().max().item(), 1e-12)
         assert ((got[off:off + n] - gw).abs().max().item() / scale) < 2e-4 or scale < 1e-10, name
+
+
+def test_heads_role_joins_are_race_free(built_lib):
+    """The fused heads run as three workgroups per sample that meet through an agent-scope counter (heads_fused.inc): the
+    last arriver adds the log-prob parts (forward) / folds the focused-atom chains into d A3 (backward).  Repeated runs of
+    the same mini-batch must give bit-identical predictions and, up to the order of the f32 atomics of the encoder
+    adjoint, the same gradient -- whichever workgroup happens to arrive last."""
+    from molgym_amd.agents.covariant import CovariantAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS
+    cfg = CONFIGS['cfg2']
+    torch.manual_seed(3)
+    ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']), bag_scale=cfg['bag_scale'],
+                     beta=cfg['beta'], device=torch.device('cuda'), **MODEL_DEFAULTS)
+    data = make_batch(cfg['batch'], cfg['canvas_size'], cfg['zs'], seed=11)
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    ref_pred, ref_grad = None, None
+    for it in range(200):
+        ac.theta.grad.zero_()
+        with torch.no_grad():
+            pred = ac.forward_batch(batch).clone()
+        ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+        g = ac.theta.grad.clone()
+        if ref_pred is None:
+            ref_pred, ref_grad = pred, g
+            continue
+        assert torch.equal(pred, ref_pred), f'predictions changed on repetition {it}'
+        assert (g - ref_grad).abs().max().item() <= 2e-5 * ref_grad.abs().max().item(), f'gradient changed on repetition {it}'
