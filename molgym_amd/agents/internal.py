@@ -149,14 +149,10 @@ class SchNetAC(FlatThetaAgent):
             # every bias starts at zero
         return theta
 
-    def make_batch(self, observations: List[ObservationType], actions: np.ndarray) -> IntBatch:
+    def _parse(self, observations: List[ObservationType]):
+        """What make_batch needs from the observations alone (the rollout step parses once for its five passes)."""
         N, B = self.num_atoms, len(observations)
         pos32, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
-        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
-        assert acts.shape == (B, 7)
-        focus, element = np.rint(acts[:, 1]).astype(np.int64), np.rint(acts[:, 2]).astype(np.int64)
-        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= self.num_zs:
-            raise RuntimeError('index out of range in one-hot selection')
         # exact float64 positions for the z-matrix step, as the reference (ase.Atoms positions are float64)
         pos64 = np.zeros((B, N, 3))
         for b, (canvas, _) in enumerate(observations):
@@ -165,6 +161,16 @@ class SchNetAC(FlatThetaAgent):
                 if self.zs[label] != 0:
                     pos64[b, k] = xyz
                     k += 1
+        return charges, bags, natoms, pos64
+
+    def make_batch(self, observations: List[ObservationType], actions: np.ndarray, parsed=None) -> IntBatch:
+        N, B = self.num_atoms, len(observations)
+        charges, bags, natoms, pos64 = parsed if parsed is not None else self._parse(observations)
+        acts = np.ascontiguousarray(np.asarray(actions, dtype=np.float32))
+        assert acts.shape == (B, 7)
+        focus, element = np.rint(acts[:, 1]).astype(np.int64), np.rint(acts[:, 2]).astype(np.int64)
+        if focus.min() < 0 or focus.max() >= N or element.min() < 0 or element.max() >= self.num_zs:
+            raise RuntimeError('index out of range in one-hot selection')
         a64 = np.asarray(actions, dtype=np.float32).astype(np.float64)  # the agent casts actions to its dtype
         new_p = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], a64[:, 5])
         new_m = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], -a64[:, 5])
@@ -210,6 +216,22 @@ class SchNetAC(FlatThetaAgent):
                               np.array([sign * dihedral]))[0]
         index = self.action_space.zs.index(self.observation_space.zs[element])
         return index, tuple(float(x) for x in new)
+
+    def _actions_to_space(self, acts: np.ndarray, pos64: np.ndarray, natoms: np.ndarray):
+        """to_action_space for a whole batch of action rows: ONE vectorised z-matrix placement instead of one per sample
+        (140 single placements are 13 ms of numpy call overhead; this is 0.2 ms) -- same arithmetic, same float64 inputs."""
+        a64 = np.asarray(acts, dtype=np.float32).astype(np.float64)
+        focus, element = np.rint(a64[:, 1]).astype(np.int64), np.rint(a64[:, 2]).astype(np.int64)
+        sign = np.where(np.rint(a64[:, 6]) != 0, -1.0, 1.0)
+        new = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], sign * a64[:, 5])
+        out = []
+        for b in range(len(a64)):
+            if a64[b, 0]:
+                out.append(None)
+                continue
+            index = self.action_space.zs.index(self.observation_space.zs[int(element[b])])
+            out.append((index, tuple(float(x) for x in new[b])))
+        return out
 
     def _forward_nograd(self, batch: IntBatch):
         lib = _lib.lib()
@@ -272,14 +294,15 @@ class SchNetAC(FlatThetaAgent):
         exactly what step(obs, actions) returns for them."""
         B, N, Z = len(observations), self.num_atoms, self.num_zs
         dev = self.theta.device
-        _, _, bags, natoms = parse_observations_host(observations, self.zs, N)
+        parsed = self._parse(observations)
+        _, bags, natoms, pos64 = parsed
         acts = np.zeros((B, 7), dtype=np.float32)  # stop = 0: this agent does not stop
         acts[:, 3] = 0.5 * (self.min_distance + self.max_distance)  # harmless placeholders for the early passes
         acts[:, 4] = acts[:, 5] = 0.5 * np.pi
         nat = torch.from_numpy(natoms.astype(np.int64)).to(dev)
         with torch.no_grad():
             # focus (agent.py:206-221): softmax over the real atoms; an empty canvas focuses slot 0
-            batch = self.make_batch(observations, acts)
+            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             logit_f = self._ws_view(batch.cfg, ws, 'logitF')[:batch.cfg.TA]
             dense = torch.full((B, N), float('-inf'), device=dev)
@@ -290,7 +313,7 @@ class SchNetAC(FlatThetaAgent):
             focus = torch.distributions.Categorical(probs=p_f).sample() if self.training else torch.argmax(p_f, -1)
             acts[:, 1] = focus.cpu().numpy()
             # element (agent.py:229-242): softmax over the elements left in the bag
-            batch = self.make_batch(observations, acts)
+            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             logit_e = self._ws_view(batch.cfg, ws, 'logitE')[:B * Z].view(B, Z)
             mask_e = torch.from_numpy(bags > 0).to(dev)
@@ -300,7 +323,7 @@ class SchNetAC(FlatThetaAgent):
             element = torch.distributions.Categorical(probs=p_e).sample() if self.training else torch.argmax(p_e, -1)
             acts[:, 2] = element.cpu().numpy()
             # distance / angle / dihedral (agent.py:246-292): Normal around tanh(mean) * width / 2 + center
-            batch = self.make_batch(observations, acts)
+            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             cout = self._ws_view(batch.cfg, ws, 'cout')[:B * 3].view(B, 3)
             half_w = torch.tensor([0.5 * (self.max_distance - self.min_distance), 0.5 * np.pi, 0.5 * np.pi], device=dev)
@@ -315,23 +338,24 @@ class SchNetAC(FlatThetaAgent):
                 cont = mean
             acts[:, 3:6] = cont.cpu().numpy()
             # kappa (agent.py:294-315): keep / flip the dihedral, logits from the two hypothetical placements
-            batch = self.make_batch(observations, acts)
+            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             kv = self._ws_view(batch.cfg, ws, 'kv')[:2 * B].view(2, B).t()
             kappa = torch.distributions.Categorical(logits=kv).sample() if self.training else torch.argmax(kv, -1)
             acts[:, 6] = kappa.cpu().numpy()
-            batch = self.make_batch(observations, acts)
+            batch = self.make_batch(observations, acts, parsed)
             out, _ = self._forward_nograd(batch)
         return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2],
-                'actions': [self.to_action_space(a, o) for a, o in zip(acts, observations)]}
+                'actions': self._actions_to_space(acts, pos64, natoms)}
 
     def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
         if self.theta.device.type != 'cuda':
             raise RuntimeError('SchNetAC runs on the HIP device only (no CPU fallback)')
         if actions is None:
             return self._step_sample(observations)
-        batch = self.make_batch(observations, actions)
+        parsed = self._parse(observations)
+        batch = self.make_batch(observations, actions, parsed)
         out = _IntStep.apply(self.theta, self, batch)
         acts = np.asarray(actions, dtype=np.float32)
         return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2],
-                'actions': [self.to_action_space(a, o) for a, o in zip(acts, observations)]}
+                'actions': self._actions_to_space(acts, parsed[3], parsed[2])}

@@ -98,3 +98,30 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_internal_batched_action_conversion_equals_per_sample():
+    """SchNetAC's rollout step converts the drawn action rows with ONE vectorised z-matrix placement
+    (`_actions_to_space`); it must give exactly what `to_action_space` (internal/agent.py:91-110) gives row by row,
+    including the kappa sign flip and canvases of 0, 1 and 2 atoms (the fixed-axis special cases of zmat.py)."""
+    import numpy as np
+    from molgym_amd.agents.internal import SchNetAC
+    from molgym_amd.spaces import ActionSpace, ObservationSpace
+    from molgym_amd.synthetic import CONFIGS, make_batch
+    cfg = CONFIGS['cfg2']
+    ia = SchNetAC.__new__(SchNetAC)  # host-side helpers only: no device, no parameters
+    ia.observation_space, ia.action_space = ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs'])
+    ia.zs, ia.num_atoms, ia.num_zs = list(cfg['zs']), cfg['canvas_size'], len(cfg['zs'])
+    data = make_batch(80, cfg['canvas_size'], cfg['zs'], seed=1)
+    rng = np.random.default_rng(0)
+    _, _, natoms, pos64 = ia._parse(data['obs'])
+    assert {0, 1, 2} <= set(natoms.tolist())
+    acts = np.zeros((80, 7), dtype=np.float32)
+    acts[:, 1] = [rng.integers(0, max(n, 1)) for n in natoms]
+    acts[:, 2] = rng.integers(1, 3, 80)
+    acts[:, 3], acts[:, 4], acts[:, 5] = rng.uniform(0.8, 1.8, 80), rng.uniform(0.2, 2.9, 80), rng.uniform(0.1, 3.0, 80)
+    acts[:, 6] = rng.integers(0, 2, 80)
+    got = ia._actions_to_space(acts, pos64, natoms)
+    want = [ia.to_action_space(a, o) for a, o in zip(acts, data['obs'])]
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and np.array_equal(np.asarray(g[1]), np.asarray(w[1]), equal_nan=True)
