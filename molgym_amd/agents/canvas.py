@@ -54,14 +54,24 @@ class DeviceCanvas:
         if len(indices) == 0:
             return
         pos, charges, bags, natoms = parse_canvases_f64(observations, self.zs, self.N)
-        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.pos64.device)
-        dev = self.pos64.device
-        p = torch.from_numpy(pos).to(dev)
+        # ONE host-to-device copy: [positions | charges | bag | atom count | row index] per environment as float64 (all
+        # integers here are exact in it); the five scatters below are device-side (five separate small uploads cost 2.5 ms
+        # for 20 environments, more than five rollout steps)
+        k, N, Z = len(indices), self.N, len(self.zs)
+        packed = np.empty((k, 4 * N + Z + 2), dtype=np.float64)
+        packed[:, :3 * N] = pos.reshape(k, 3 * N)
+        packed[:, 3 * N:4 * N] = charges
+        packed[:, 4 * N:4 * N + Z] = bags
+        packed[:, 4 * N + Z] = natoms
+        packed[:, 4 * N + Z + 1] = np.asarray(indices, dtype=np.int64)
+        buf = torch.from_numpy(packed).to(self.pos64.device)
+        idx = buf[:, 4 * N + Z + 1].long()
+        p = buf[:, :3 * N].reshape(k, N, 3)
         self.pos64[idx] = p
         self.pos32[idx] = p.float()
-        self.charges[idx] = torch.from_numpy(charges).to(dev)
-        self.bags[idx] = torch.from_numpy(bags).to(dev)
-        self.natoms_dev[idx] = torch.from_numpy(natoms).to(dev)
+        self.charges[idx] = buf[:, 3 * N:4 * N].to(self.charges.dtype)
+        self.bags[idx] = buf[:, 4 * N:4 * N + Z].to(self.bags.dtype)
+        self.natoms_dev[idx] = buf[:, 4 * N + Z].to(self.natoms_dev.dtype)
         self.natoms[np.asarray(indices)] = natoms
         self.bags_host[np.asarray(indices)] = bags.astype(np.int64)
 
