@@ -110,6 +110,14 @@ int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos,
 int mg_canvas_append(int32_t B, int32_t N, int32_t Z, const int32_t* zs_host, const float* actions, double* pos64,
                      float* pos32, int32_t* charges, float* bags, int32_t* natoms, double* newpos, void* stream);
 
+/* ---- mini-batch gather (replaces collect_data_batch, molgym/ppo.py:77-81, on a rollout parked in HBM) ----------------
+ * dst[f][b][:] = src[f][idx[b]][:] for nf <= 8 row-major matrices in ONE launch; row_bytes[f] (multiples of 4) are HOST
+ * values, src / dst are HOST arrays of device pointers, idx [B] int64 on the device.  ppo.train draws a new permutation
+ * every epoch, so every mini-batch is a gather of positions, charges, bags, action rows and the three float64 columns of
+ * the loss: seven index_select calls cost more host time than the forward pass's launches.                            */
+int mg_gather_rows(int32_t nf, const void* const* src, void* const* dst, const int32_t* row_bytes, const int64_t* idx,
+                   int32_t B, void* stream);
+
 /* Input validation of the forward that just ran on `ws`: synchronises `stream`, then MG_EINVAL if the list build found
  * real atoms that are not compacted to the front of their canvas, or cfg.TA / cfg.TE inconsistent with `charges`
  * (the forward itself never synchronises, so it cannot report these).                                              */

@@ -43,6 +43,7 @@ SYMBOLS = {
     'mg_cov_sample': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, _P, C.c_size_t, _P, _P, _P]),
     'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     'mg_canvas_append': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'mg_gather_rows': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P, C.c_int32, _P]),
     'mg_cov_check': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P]),
     'mg_cov_head_outputs': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P, _P]),
     'mg_so3_density': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P, C.c_int32, _P, _P]),
@@ -83,3 +84,29 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError(f'molgym_hip error {rc}: {lib().mg_last_error().decode()}')
+
+
+def gather_rows(tensors, idx_dev, stream_ptr):
+    """rows `idx_dev` (int64, on the device) of up to 8 row-major device tensors in ONE launch (mg_gather_rows); the results
+    are views of one allocation, each contiguous.  Replaces one index_select per tensor (host time, not device time, is
+    what those cost on a 140-sample mini-batch)."""
+    import torch
+    B = int(idx_dev.numel())
+    nf = len(tensors)
+    rb = [int(t[0].numel() * t.element_size()) if t.dim() > 1 else int(t.element_size()) for t in tensors]
+    offs, total = [], 0
+    for r in rb:
+        offs.append(total)
+        total += (B * r + 63) // 64 * 64
+    buf = torch.empty(max(total, 64), dtype=torch.uint8, device=idx_dev.device)
+    outs = []
+    for t, r, o in zip(tensors, rb, offs):
+        outs.append(buf[o:o + B * r].view(t.dtype).view((B, ) + tuple(t.shape[1:])))
+    if B == 0:
+        return outs
+    src = (C.c_void_p * nf)(*[t.data_ptr() for t in tensors])
+    dst = (C.c_void_p * nf)(*[buf.data_ptr() + o for o in offs])
+    rbs = (C.c_int32 * nf)(*rb)
+    check(lib().mg_gather_rows(nf, src, dst, rbs, C.c_void_p(idx_dev.data_ptr()), B, stream_ptr))
+    return outs
+

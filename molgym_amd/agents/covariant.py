@@ -69,9 +69,12 @@ class RolloutOnDevice:
         self.ac, self.natoms = ac, natoms
         self.t = (pos, charges, bags, actions, logp, adv, ret)
 
-    def minibatch(self, indices: np.ndarray) -> DeviceBatch:
-        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(self.t[0].device)
-        pos, charges, bags, actions, logp, adv, ret = (x.index_select(0, idx) for x in self.t)
+    def minibatch(self, indices: np.ndarray, idx_dev: Optional[torch.Tensor] = None) -> DeviceBatch:
+        """`idx_dev`: the same indices already on the device (ppo.train uploads an epoch's permutation once)"""
+        if idx_dev is None:
+            idx_dev = torch.as_tensor(np.asarray(indices, dtype=np.int64)).to(self.t[0].device)
+        with torch.cuda.device(self.t[0].device):
+            pos, charges, bags, actions, logp, adv, ret = _lib.gather_rows(self.t, idx_dev, _stream(self.t[0].device))
         return DeviceBatch(self.ac._make_cfg(len(indices), self.natoms[indices]), pos, charges, bags, actions, logp,
                            adv, ret)
 

@@ -71,11 +71,14 @@ class IntRollout:
         f64 = lambda x: x.to(dev) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
         self.logp, self.adv, self.ret = f64(data['logp']), f64(data['adv']), f64(data['ret'])
 
-    def minibatch(self, indices: np.ndarray) -> IntBatch:
+    def minibatch(self, indices: np.ndarray, idx_dev: Optional[torch.Tensor] = None) -> IntBatch:
         idx = np.asarray(indices, dtype=np.int64)
         batch = self.ac.make_batch([self.obs[i] for i in idx], self.act[idx])
-        d_idx = torch.from_numpy(idx).to(self.logp.device)
-        batch.logp, batch.adv, batch.ret = (x.index_select(0, d_idx) for x in (self.logp, self.adv, self.ret))
+        if idx_dev is None:
+            idx_dev = torch.from_numpy(idx).to(self.logp.device)
+        with torch.cuda.device(self.logp.device):
+            batch.logp, batch.adv, batch.ret = _lib.gather_rows((self.logp, self.adv, self.ret), idx_dev,
+                                                                _stream(self.logp.device))
         return batch
 
 

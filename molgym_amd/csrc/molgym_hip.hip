@@ -49,6 +49,24 @@ static int ensure_tables() {
 
 extern "C" const char* mg_last_error(void) { return g_err; }
 
+extern "C" int mg_gather_rows(int32_t nf, const void* const* src, void* const* dst, const int32_t* row_bytes, const int64_t* idx,
+                              int32_t B, void* stream) {
+  if (nf < 0 || nf > 8) MG_FAIL(MG_EINVAL, "mg_gather_rows: %d matrices (at most 8)", nf);
+  if (B <= 0 || nf == 0) return MG_OK;
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nf = nf;
+  for (int f = 0; f < nf; ++f) {
+    if (row_bytes[f] <= 0 || row_bytes[f] % 4) MG_FAIL(MG_EINVAL, "mg_gather_rows: row of %d bytes", row_bytes[f]);
+    a.src[f] = reinterpret_cast<const unsigned*>(src[f]);
+    a.dst[f] = reinterpret_cast<unsigned*>(dst[f]);
+    a.row_words[f] = row_bytes[f] / 4;
+  }
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, a, reinterpret_cast<const long long*>(idx), B);
+  LAUNCH_CHECK();
+  return MG_OK;
+}
+
 extern "C" int mg_profile_enable(int on) {
   for (auto& sp : g_spans) { prof_flush(sp); sp.total_ms = 0; sp.count = 0; }
   g_prof_on = on ? 1 : 0;

@@ -116,28 +116,41 @@ class _DeviceRunner:
         if self.dev.type == 'cuda' and len(data['obs']) > mini_batch_size:
             self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
 
+    def set_epoch(self, locals_: Sequence[np.ndarray]):
+        """this rank's sample indices of every mini-batch of the epoch: ONE upload; `run` hands device views of it to the
+        gather (a 140-sample mini-batch spent more host time on its own index upload + seven index_select calls than on
+        the forward and backward launches)"""
+        sizes = [len(x) for x in locals_]
+        flat = np.concatenate([np.asarray(x, dtype=np.int64) for x in locals_]) if sizes else np.zeros(0, dtype=np.int64)
+        self._idx = torch.from_numpy(flat).to(self.dev) if self.dev.type == 'cuda' else None
+        self._off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
     def begin_epoch(self):
         for p in self.ac.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         for st in self.streams:
-            st.wait_stream(torch.cuda.current_stream(self.dev))
+            st.wait_stream(torch.cuda.current_stream(self.dev))  # (also orders the index upload before the gathers)
+
+    def _minibatch(self, mb_index: int, local: np.ndarray):
+        idx = getattr(self, '_idx', None)
+        if idx is None:
+            return self.rollout.minibatch(local)
+        lo, hi = int(self._off[mb_index]), int(self._off[mb_index + 1])
+        assert hi - lo == len(local)
+        return self.rollout.minibatch(local, idx[lo:hi])
 
     def run(self, mb_index: int, local: np.ndarray, scale: float) -> torch.Tensor:
         if len(local) == 0:  # this rank's slice of a small remainder mini-batch
             return torch.zeros(6, dtype=torch.float64, device=self.dev)
-        mb = self.rollout.minibatch(local)
         if not self.streams:
-            return self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale) * scale
+            return self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale) * scale
         slot = mb_index % len(self.streams)
         st = self.streams[slot]
-        st.wait_stream(torch.cuda.current_stream(self.dev))  # the gather above ran there
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st):  # gather and step on the mini-batch's own stream: no cross-stream hand-off
+            mb = self._minibatch(mb_index, local)
             stats = self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale, slot=slot) * scale
-        for t in vars(mb).values():
-            if torch.is_tensor(t):
-                t.record_stream(st)
-        stats.record_stream(st)
+        stats.record_stream(torch.cuda.current_stream(self.dev))
         return stats
 
     def end_epoch(self):
@@ -147,6 +160,9 @@ class _DeviceRunner:
 
 class _AutogradRunner:
     """Any AbstractActorCritic: compute_loss + loss.backward() per mini-batch (ppo.py:122-131)."""
+
+    def set_epoch(self, locals_):
+        pass
 
     def __init__(self, ac, data, mini_batch_size, hp, device=None):
         self.ac, self.data, self.hp, self.device = ac, data, hp, device
@@ -189,12 +205,14 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
     num_epochs = 0
     for i in range(max_num_steps):
         optimizer.zero_grad()
-        runner.begin_epoch()
-        batch_stats = []
-        for mb_index, batch_indices in enumerate(_epoch_batches(num_samples, mini_batch_size, dist, rank)):
+        slices = []  # (this rank's slice, its share) of every mini-batch of the epoch
+        for batch_indices in _epoch_batches(num_samples, mini_batch_size, dist, rank):
             n_glob = len(batch_indices)
             lo, hi = (rank * n_glob) // world, ((rank + 1) * n_glob) // world
-            batch_stats.append(runner.run(mb_index, batch_indices[lo:hi], (hi - lo) / n_glob))
+            slices.append((batch_indices[lo:hi], (hi - lo) / n_glob))
+        runner.set_epoch([sl for sl, _ in slices])
+        runner.begin_epoch()
+        batch_stats = [runner.run(mb_index, sl, share) for mb_index, (sl, share) in enumerate(slices)]
         runner.end_epoch()
         stats = torch.stack(batch_stats).mean(dim=0)  # mean of mini-batch means (ppo.py:92-95)
         if dist is not None:

@@ -191,3 +191,21 @@ def test_train_reports_the_reference_gradient_norm_and_clips(built_lib):
                       target_kl=1e9, vf_coef=0.5, entropy_coef=0.01, gradient_clip=0.5, max_num_steps=1)
     assert abs(infos['grad_norm'] - want_norm) < 1e-4 * want_norm and want_norm > 0.5
     assert (ac.theta.detach() - p.detach()).abs().max().item() < 1e-6
+
+
+def test_gather_rows_equals_index_select(built_lib):
+    """mg_gather_rows (one launch for all the tensors of a mini-batch) against torch.index_select, mixed dtypes / widths,
+    repeated and unsorted indices, and the empty selection"""
+    g = torch.Generator().manual_seed(0)
+    n = 1000
+    ts = (torch.randn(n, 7, 3, generator=g).cuda(), torch.randint(0, 17, (n, 7), generator=g, dtype=torch.int32).cuda(),
+          torch.randn(n, 3, generator=g).cuda(), torch.randn(n, 6, generator=g).cuda(),
+          torch.randn(n, generator=g, dtype=torch.float64).cuda(), torch.randn(n, generator=g, dtype=torch.float64).cuda(),
+          torch.randn(n, generator=g, dtype=torch.float64).cuda())
+    for B in (0, 1, 140, 999):
+        idx = torch.randint(0, n, (B, ), generator=g).cuda()
+        got = _lib.gather_rows(ts, idx, S())
+        for a, t in zip(got, ts):
+            want = t.index_select(0, idx)
+            assert a.dtype == t.dtype and a.shape == want.shape and a.is_contiguous()
+            assert torch.equal(a, want)
