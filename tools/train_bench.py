@@ -1,6 +1,6 @@
 """Debug tool (GPU box): wall-clock throughput of molgym_amd.ppo.train (prepare_rollout + epochs of mini-batches + norm /
 clip / Adam) on a synthetic rollout -- what a user of the loop sees, next to the kernel-only number of bench.py.
-usage: python tools/train_bench.py [config] [rollout samples] [mini batch] [epochs]"""
+usage: python tools/train_bench.py [config | internal] [rollout samples] [mini batch] [epochs]"""
 import sys
 import time
 
@@ -16,11 +16,18 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1400
 mb = int(sys.argv[3]) if len(sys.argv) > 3 else 140
 epochs = int(sys.argv[4]) if len(sys.argv) > 4 else 7
-cfg = CONFIGS[name]
 torch.manual_seed(0)
-ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']), bag_scale=cfg['bag_scale'],
-                 beta=cfg['beta'], device=torch.device('cuda'), **MODEL_DEFAULTS)
-d = make_batch(n, cfg['canvas_size'], cfg['zs'], seed=0)
+if name == 'internal':  # SchNetAC on BASELINE configs[0]
+    from molgym_amd.agents.internal import SchNetAC
+    from molgym_amd.synthetic import make_batch_internal
+    zs = [0, 9, 16]
+    ac = SchNetAC(ObservationSpace(7, zs), ActionSpace(zs), (0.8, 1.8), 128, device='cuda:0')
+    d = make_batch_internal(n, 7, zs, seed=0)
+else:
+    cfg = CONFIGS[name]
+    ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']), bag_scale=cfg['bag_scale'],
+                     beta=cfg['beta'], device=torch.device('cuda'), **MODEL_DEFAULTS)
+    d = make_batch(n, cfg['canvas_size'], cfg['zs'], seed=0)
 data = {'obs': d['obs'], 'act': d['act'], 'logp': d['logp'], 'adv': d['adv'], 'ret': d['ret']}
 opt = torch.optim.Adam(ac.parameters(), lr=1e-5)
 for rep in range(3):
