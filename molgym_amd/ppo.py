@@ -111,6 +111,8 @@ class _DeviceRunner:
     def __init__(self, ac, data, mini_batch_size, hp):
         self.ac, self.hp = ac, hp
         self.rollout = ac.prepare_rollout(data)
+        self.num_samples, self._whole = len(data['obs']), None
+        self.world = _dist()[2]
         self.dev = next(ac.parameters()).device
         self.streams = []
         if self.dev.type == 'cuda' and len(data['obs']) > mini_batch_size:
@@ -133,6 +135,12 @@ class _DeviceRunner:
             st.wait_stream(torch.cuda.current_stream(self.dev))  # (also orders the index upload before the gathers)
 
     def _minibatch(self, mb_index: int, local: np.ndarray):
+        if len(local) == self.num_samples and self.world == 1:
+            # the mini-batch IS the rollout: a permutation of all samples changes neither the loss (a mean) nor the
+            # gradient (a sum): one gather for all epochs
+            if self._whole is None:
+                self._whole = self.rollout.minibatch(np.arange(self.num_samples))
+            return self._whole
         idx = getattr(self, '_idx', None)
         if idx is None:
             return self.rollout.minibatch(local)
@@ -222,7 +230,9 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
                     p.grad = torch.zeros_like(p)
                 dist.all_reduce(p.grad)
         if flat:
-            host = torch.cat([stats, ac.grad_norm_clip(0.0).double()]).tolist()  # the epoch's only device -> host copy
+            # norm AND clip in one call, ahead of the KL test: the norm reported is the pre-clip one, and when the test stops
+            # the loop the (clipped) gradient is discarded anyway (ppo.py:135-144 breaks before the step)
+            host = torch.cat([stats, ac.grad_norm_clip(gradient_clip).double()]).tolist()  # the epoch's only device -> host copy
             loss_info = dict(zip(KEYS, host[:6]))
             loss_info['grad_norm'] = host[6]
         else:
@@ -231,9 +241,7 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
         if loss_info['approx_kl'] > 1.5 * target_kl:
             logging.debug(f'Early stopping at step {i} for reaching max KL.')
             break
-        if flat:
-            ac.grad_norm_clip(gradient_clip)
-        else:
+        if not flat:
             torch.nn.utils.clip_grad_norm_(ac.parameters(), max_norm=gradient_clip)
         optimizer.step()
         optimizer.zero_grad()
