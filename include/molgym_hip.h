@@ -193,6 +193,17 @@ int mg_adv_normalize(int32_t T, double* adv, double* scratch2, void* stream);
  * If max_norm > 0: g *= min(1, max_norm/(norm+1e-6)).                                   */
 int mg_grad_norm_clip(int64_t n, float* grad, float max_norm, float* norm_out, void* stream);
 
+/* One Adam update of the flat parameter vector (replaces optimizer.step(), molgym/ppo.py:145, for torch.optim.Adam on the
+ * single flat theta): the arithmetic of torch.optim.Adam's foreach implementation in one launch --
+ *   grad' = (maximize ? -grad : grad) + weight_decay * param;  exp_avg.lerp_(grad', 1 - beta1);
+ *   exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad'^2;  [amsgrad: max_exp_avg_sq = max(max_exp_avg_sq, exp_avg_sq)]
+ *   param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq or its running max) / sqrt(1 - beta2^step) + eps)
+ * on the optimizer's OWN state tensors (so optimizer.state_dict() stays what torch would have produced).
+ * `step` is the count AFTER this update (>= 1); max_exp_avg_sq may be null (amsgrad off); all arrays [n] f32 on the device. */
+int mg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int32_t maximize,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,42 @@ class FlatThetaAgent(AbstractActorCritic):
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.theta.device).cuda_stream)
 
+    def adam_step(self, optimizer) -> bool:
+        """optimizer.step() (ppo.py:145) for a plain torch.optim.Adam over the flat theta as ONE HIP launch (mg_adam_step)
+        on the optimizer's own state tensors, which are created exactly as torch creates them -- so state_dict(), learning-
+        rate schedulers and a later optimizer.step() see nothing unusual.  Returns False (nothing done) for anything else:
+        another optimizer class, several parameter groups / tensors, fused / capturable / differentiable variants."""
+        from .. import _lib
+        if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+            return False
+        g = optimizer.param_groups[0]
+        p = self.theta
+        if len(g['params']) != 1 or g['params'][0] is not p or p.grad is None or not p.is_cuda:
+            return False
+        if g.get('capturable') or g.get('fused') or g.get('differentiable') or torch.is_tensor(g['lr']):
+            return False
+        if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.grad.is_contiguous():
+            return False
+        st = optimizer.state[p]
+        if len(st) == 0:  # torch.optim.Adam._init_group
+            st['step'] = torch.tensor(0.0, dtype=torch.float64 if torch.get_default_dtype() == torch.float64 else torch.float32)
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if g['amsgrad']:
+                st['max_exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if g['amsgrad'] and 'max_exp_avg_sq' not in st:
+            return False
+        st['step'] += 1
+        step = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
+        beta1, beta2 = g['betas']
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        with self._guard():
+            _lib.check(_lib.lib().mg_adam_step(p.numel(), ptr(p.data), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']),
+                                               ptr(st['max_exp_avg_sq']) if g['amsgrad'] else None, float(g['lr']),
+                                               float(beta1), float(beta2), float(g['eps']), float(g['weight_decay']), step,
+                                               1 if g.get('maximize') else 0, self._s()))
+        return True
+
     def grad_norm_clip(self, max_norm: float = 0.0) -> torch.Tensor:
         """||theta.grad||_2 as a 1-element device tensor (util.compute_gradient_norm, tools/util.py:61-69) and, if
         max_norm > 0, theta.grad *= min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_, ppo.py:144) -- one C call on

@@ -243,7 +243,8 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
             break
         if not flat:
             torch.nn.utils.clip_grad_norm_(ac.parameters(), max_norm=gradient_clip)
-        optimizer.step()
+        if not (flat and hasattr(ac, 'adam_step') and ac.adam_step(optimizer)):  # one launch for Adam on the flat theta
+            optimizer.step()
         optimizer.zero_grad()
         num_epochs += 1
         infos.update(loss_info)

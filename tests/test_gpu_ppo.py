@@ -209,3 +209,28 @@ def test_gather_rows_equals_index_select(built_lib):
             want = t.index_select(0, idx)
             assert a.dtype == t.dtype and a.shape == want.shape and a.is_contiguous()
             assert torch.equal(a, want)
+
+
+@pytest.mark.parametrize('amsgrad,wd,maximize', [(True, 0.0, False), (False, 0.0, False), (True, 1e-2, False), (False, 0.0, True)])
+def test_adam_step_kernel_equals_torch_adam(built_lib, amsgrad, wd, maximize):
+    """mg_adam_step (through FlatThetaAgent.adam_step) against torch.optim.Adam itself over several updates: parameters and
+    every state tensor, and the optimizer's own state_dict stays interchangeable (a torch step after ours continues it)."""
+    ac, _, _ = make_pair('cfg2', seed=5)
+    ref = torch.nn.Parameter(ac.theta.detach().clone())
+    kw = dict(lr=3e-4, amsgrad=amsgrad, weight_decay=wd, maximize=maximize)
+    ours, theirs = torch.optim.Adam(ac.parameters(), **kw), torch.optim.Adam([ref], **kw)
+    g = torch.Generator().manual_seed(1)
+    for it in range(6):
+        grad = (torch.randn(ac.theta.numel(), generator=g) * (10.0 ** float(torch.randint(-3, 2, (1, ), generator=g)))).cuda()
+        ac.theta.grad, ref.grad = grad.clone(), grad.clone()
+        if it < 5:
+            assert ac.adam_step(ours) is True
+        else:
+            ours.step()  # torch continues from the state our launches left
+        theirs.step()
+        so, st = ours.state[ac.theta], theirs.state[ref]
+        assert float(so['step']) == float(st['step']) == it + 1
+        for k in ('exp_avg', 'exp_avg_sq') + (('max_exp_avg_sq', ) if amsgrad else ()):
+            torch.testing.assert_close(so[k], st[k], rtol=2e-6, atol=1e-12)
+        torch.testing.assert_close(ac.theta.detach(), ref.detach(), rtol=1e-6, atol=1e-9)
+    assert ac.adam_step(torch.optim.SGD(ac.parameters(), lr=0.1)) is False  # anything else is left to torch
