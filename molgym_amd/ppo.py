@@ -152,7 +152,8 @@ class _DeviceRunner:
         if len(local) == 0:  # this rank's slice of a small remainder mini-batch
             return torch.zeros(6, dtype=torch.float64, device=self.dev)
         if not self.streams:
-            return self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale) * scale
+            stats = self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale)
+            return stats if scale == 1.0 else stats * scale
         slot = mb_index % len(self.streams)
         st = self.streams[slot]
         with torch.cuda.stream(st):  # gather and step on the mini-batch's own stream: no cross-stream hand-off
@@ -222,7 +223,8 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
         runner.begin_epoch()
         batch_stats = [runner.run(mb_index, sl, share) for mb_index, (sl, share) in enumerate(slices)]
         runner.end_epoch()
-        stats = torch.stack(batch_stats).mean(dim=0)  # mean of mini-batch means (ppo.py:92-95)
+        # mean of mini-batch means (ppo.py:92-95)
+        stats = batch_stats[0] if len(batch_stats) == 1 else torch.stack(batch_stats).mean(dim=0)
         if dist is not None:
             dist.all_reduce(stats)
             for p in ac.parameters():
