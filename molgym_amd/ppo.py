@@ -123,6 +123,9 @@ class _DeviceRunner:
         gather (a 140-sample mini-batch spent more host time on its own index upload + seven index_select calls than on
         the forward and backward launches)"""
         sizes = [len(x) for x in locals_]
+        if self.world == 1 and sizes == [self.num_samples]:  # the whole rollout at once: gathered once (_minibatch)
+            self._idx = None
+            return
         flat = np.concatenate([np.asarray(x, dtype=np.int64) for x in locals_]) if sizes else np.zeros(0, dtype=np.int64)
         self._idx = torch.from_numpy(flat).to(self.dev) if self.dev.type == 'cuda' else None
         self._off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
