@@ -1,5 +1,6 @@
 // molgym_hip.hip -- C-ABI entry points (include/molgym_hip.h) for the gfx950 PPO hot path.
 // One translation unit: kernels live in the .inc files next to this one.
+#include <mutex>
 #include "state.inc"
 #include "sampling.inc"
 #include "heads_fused.inc"
@@ -10,8 +11,11 @@
 #include "canvas.inc"
 
 static bool g_tables_ready[MG_MAX_DEVICES];  // hipMemcpyToSymbol fills the CURRENT device's copy of a __constant__
+static std::mutex g_tables_mutex;
 static int ensure_tables() {
   const int dev = cur_device();
+  if (g_tables_ready[dev]) return MG_OK;
+  std::lock_guard<std::mutex> lock(g_tables_mutex);  // first use from several host threads at once
   if (g_tables_ready[dev]) return MG_OK;
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_nblk), h_cg_nblk, sizeof(h_cg_nblk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cg_row_base), h_cg_row_base, sizeof(h_cg_row_base)));
