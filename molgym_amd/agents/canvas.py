@@ -21,17 +21,10 @@ from .. import _lib
 def parse_canvases_f64(observations, zs, canvas_size):
     """(pos float64 (B, N, 3), charges int32, bags float32, natoms): like parse_observations_host but keeping the
     environment's float64 positions"""
-    B = len(observations)
-    labels = np.array([[item[0] for item in obs[0]] for obs in observations], dtype=np.int64).reshape(B, canvas_size)
-    xyz = np.array([[item[1] for item in obs[0]] for obs in observations], dtype=np.float64).reshape(B, canvas_size, 3)
-    bags = np.array([obs[1] for obs in observations], dtype=np.float32).reshape(B, len(zs))
-    charges = np.asarray(zs, dtype=np.int32)[labels]
-    real = charges > 0
-    order = np.argsort(~real, axis=1, kind='stable')
-    charges = np.take_along_axis(charges, order, axis=1)
-    xyz = np.take_along_axis(xyz, order[..., None], axis=1)
-    xyz[~np.take_along_axis(real, order, axis=1)] = 0.0
-    return xyz, np.ascontiguousarray(charges), bags, real.sum(axis=1).astype(np.int32)
+    from .covariant import compact_canvases, observation_arrays
+    labels, xyz, bags = observation_arrays(observations, zs, canvas_size)
+    xyz, charges, natoms = compact_canvases(labels, xyz, zs)
+    return xyz, charges, bags.astype(np.float32), natoms.astype(np.int32)
 
 
 class DeviceCanvas:

@@ -14,6 +14,7 @@ import torch
 
 from .. import _lib, layout
 from ..lebedev import lebedev_table
+from ..observations import ParsedObservations
 from ..spaces import ActionSpace, ObservationSpace, ObservationType
 from .base import FlatThetaAgent
 from .dists import StepDists
@@ -28,30 +29,38 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def parse_observations_host(observations: List[ObservationType], zs: List[int], canvas_size: int):
-    """Observation tuples -> padded numpy arrays (agent.py:165-197, covariant/tools.py:8-49 without ase):
-    null items dropped, real atoms compacted to the front in canvas order, zero padded."""
-    B = len(observations)
-    try:
-        labels = np.array([[item[0] for item in obs[0]] for obs in observations], dtype=np.int64)
-        xyz = np.array([[item[1] for item in obs[0]] for obs in observations], dtype=np.float64)
-        bags = np.array([obs[1] for obs in observations], dtype=np.float32)
-    except ValueError as exc:  # ragged input
-        raise RuntimeError(f'malformed observations: {exc}')
-    if labels.shape != (B, canvas_size) or xyz.shape != (B, canvas_size, 3):
-        raise RuntimeError(f'canvas shape {labels.shape} does not match canvas_size {canvas_size}')
-    if bags.shape != (B, len(zs)):
-        raise RuntimeError(f'bag shape {bags.shape} does not match len(zs) {len(zs)}')
-    if labels.min(initial=0) < 0 or labels.max(initial=0) >= len(zs):
+def observation_arrays(observations, zs: List[int], canvas_size: int):
+    """(labels (B, N) int64, xyz (B, N, 3) float64, bags (B, Z) int64) of a list of observation tuples or of a
+    `ParsedObservations` (already arrays: no Python-object traversal), with the reference's shape / range errors."""
+    po = ParsedObservations.from_list(observations, canvas_size, len(zs))
+    B = len(po)
+    if po.labels.shape != (B, canvas_size) or po.xyz.shape != (B, canvas_size, 3):
+        raise RuntimeError(f'canvas shape {po.labels.shape} does not match canvas_size {canvas_size}')
+    if po.bags.shape != (B, len(zs)):
+        raise RuntimeError(f'bag shape {po.bags.shape} does not match len(zs) {len(zs)}')
+    if po.labels.min(initial=0) < 0 or po.labels.max(initial=0) >= len(zs):
         raise RuntimeError('Invalid atomic number index in canvas')
+    return po.labels, po.xyz, po.bags
+
+
+def compact_canvases(labels: np.ndarray, xyz: np.ndarray, zs: List[int]):
+    """null items dropped, real atoms compacted to the front in canvas order, zero padded (covariant/tools.py:8-49):
+    (xyz float64 (B, N, 3), charges int32 (B, N), natoms (B,))"""
     charges = np.asarray(zs, dtype=np.int32)[labels]
     real = charges > 0
     order = np.argsort(~real, axis=1, kind='stable')
     charges = np.take_along_axis(charges, order, axis=1)
     xyz = np.take_along_axis(xyz, order[..., None], axis=1)
-    natoms = real.sum(axis=1)
     xyz[~np.take_along_axis(real, order, axis=1)] = 0.0
-    return xyz.astype(np.float32), np.ascontiguousarray(charges), bags, natoms
+    return xyz, np.ascontiguousarray(charges), real.sum(axis=1)
+
+
+def parse_observations_host(observations, zs: List[int], canvas_size: int):
+    """Observation tuples (or a `ParsedObservations`) -> padded numpy arrays (agent.py:165-197, covariant/tools.py:8-49
+    without ase): null items dropped, real atoms compacted to the front in canvas order, zero padded."""
+    labels, xyz, bags = observation_arrays(observations, zs, canvas_size)
+    xyz, charges, natoms = compact_canvases(labels, xyz, zs)
+    return xyz.astype(np.float32), charges, bags.astype(np.float32), natoms
 
 
 class DeviceBatch:

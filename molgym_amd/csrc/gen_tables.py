@@ -144,6 +144,46 @@ def main():
     pidx, pair_gmax = order(pair_cnt)
     pair_perm = [pairs[i][0] * 25 + pairs[i][1] for i in pidx]
 
+    # RESOLVED lane-major tables of the adjoint rebuilds (k_catbuild_bwd_mfma): lane = one entry of the 25 x 25 adjoint
+    # moment matrix, groups of 64 lanes in the sorted work orders above, group g padded to its maximum count G[g].
+    # Slot (g, j) of lane t is ONE word pair {slice offset, coefficient} at [(slot_base[g] + j) * 64 + t]: consecutive
+    # lanes read consecutive 8-byte words (conflict-free ds_read_b64, no dependent index look-ups); padding slots have
+    # coefficient 0.  bk_*: aggregate block, entries (x, y) in key order; bp_*: symmetrised power block
+    # S[x][y] = dP[x][y] + dP[y][x], pairs x <= y (x == y counted from both sides: coefficient doubled), offsets point at
+    # the POWER entry (aggregate offset + nblk_l + 1).  *_pos: where the lane's result goes in the LDS matrix (float
+    # index x * 52 + 2 y; pairs: both mirror positions, 16 bits each), CG_POS_DUMP for padding lanes.
+    LD = 52
+    # padding lanes store their (zero) result into a spare word of the wave's LDS block: float index of entry 775 of the
+    # slice buffer that follows the 26 x 52 matrix (k_catbuild_bwd_mfma static_asserts this layout) -- no branch
+    POS_DUMP = 26 * LD + 2 * 775
+    def resolved(lanes, gmax, entries_of, pos_of, pad_pos):
+        off, cf, pos = [], [], []
+        for g, gm in enumerate(gmax):
+            grp = lanes[g * 64:(g + 1) * 64]
+            for j in range(gm):
+                for t in range(64):
+                    ent = entries_of(grp[t]) if t < len(grp) else []
+                    o, c = ent[j] if j < len(ent) else (0, 0.0)
+                    off.append(o)
+                    cf.append(c)
+            pos += [pos_of(grp[t]) if t < len(grp) else pad_pos for t in range(64)]
+        return off, cf, pos
+    def key_entries(key):
+        return [(g_pk[q] & 0xffff, t_terms[q][2]) for q in range(t_start[key], t_start[key + 1])]
+    def pair_entries(key):
+        x, y = key // 25, key % 25
+        ent = [((g_pk[q] & 0xffff) + (g_pk[q] >> 16), t_terms[q][2] * (2.0 if x == y else 1.0))
+               for q in range(t_start[key], t_start[key + 1])]
+        if x != y:
+            kb = y * 25 + x
+            ent += [((g_pk[q] & 0xffff) + (g_pk[q] >> 16), t_terms[q][2]) for q in range(t_start[kb], t_start[kb + 1])]
+        return ent
+    bk_off, bk_c, bk_pos = resolved(key_perm, key_gmax, key_entries, lambda k: (k // 25) * LD + 2 * (k % 25), POS_DUMP)
+    bp_off, bp_c, bp_pos = resolved(pair_perm, pair_gmax, pair_entries,
+                                    lambda k: ((k // 25) * LD + 2 * (k % 25)) | (((k % 25) * LD + 2 * (k // 25)) << 16),
+                                    POS_DUMP | (POS_DUMP << 16))
+    assert len(bk_off) == 64 * sum(key_gmax) and len(bp_off) == 64 * sum(pair_gmax)
+
     # forward projection, staged per part of the channel slice (parts: l <= 2, l = 3, l = 4): one word per output row,
     # t0 | count << 11 | (slice position of the aggregate entry) << 15 | (nblk_l + 1) << 25, rows of a part sorted by
     # decreasing term count and padded to groups of 64 lanes (padding: count 0, position 1023)
@@ -203,6 +243,15 @@ def main():
     w(f'static const unsigned short h_cg_pair_perm[{len(pair_perm)}] = {{' + ', '.join(map(str, pair_perm)) + '};')
     w('#define CG_PAIR_GMAX {' + ', '.join(map(str, pair_gmax)) + '}')
     w(f'#define CG_PAIR_NGRP {len(pair_gmax)}')
+    w(f'#define CG_POS_DUMP {POS_DUMP}')
+    w(f'#define CG_BK_SLOTS {sum(key_gmax)}')
+    w(f'#define CG_BP_SLOTS {sum(pair_gmax)}')
+    w(f'static const unsigned short h_cgBK_off[{len(bk_off)}] = {{' + ', '.join(map(str, bk_off)) + '};')
+    w(f'static const float h_cgBK_c[{len(bk_c)}] = {{' + ', '.join(f'{c:.9e}f' for c in bk_c) + '};')
+    w(f'static const unsigned int h_cgBK_pos[{len(bk_pos)}] = {{' + ', '.join(map(str, bk_pos)) + '};')
+    w(f'static const unsigned short h_cgBP_off[{len(bp_off)}] = {{' + ', '.join(map(str, bp_off)) + '};')
+    w(f'static const float h_cgBP_c[{len(bp_c)}] = {{' + ', '.join(f'{c:.9e}f' for c in bp_c) + '};')
+    w(f'static const unsigned int h_cgBP_pos[{len(bp_pos)}] = {{' + ', '.join(map(str, bp_pos)) + '};')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cg_tables.inc')
     text = '\n'.join(out) + '\n'
     if os.path.exists(path) and open(path).read() == text:

@@ -35,16 +35,27 @@ static int ensure_tables() {
     auto up = [](const void* src, size_t bytes, void** dst) {
       return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw;
+    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw, *bt, *bq;
+    // resolved adjoint tables: {offset, coefficient bits} word pairs, aggregate block then power block
+    static uint2 h_btab[(CG_BK_SLOTS + CG_BP_SLOTS) * 64];
+    static unsigned int h_bpos[(CG_KEY_NGRP + CG_PAIR_NGRP) * 64];
+    for (int i = 0; i < CG_BK_SLOTS * 64; ++i) { h_btab[i].x = h_cgBK_off[i]; memcpy(&h_btab[i].y, &h_cgBK_c[i], 4); }
+    for (int i = 0; i < CG_BP_SLOTS * 64; ++i) {
+      h_btab[CG_BK_SLOTS * 64 + i].x = h_cgBP_off[i];
+      memcpy(&h_btab[CG_BK_SLOTS * 64 + i].y, &h_cgBP_c[i], 4);
+    }
+    memcpy(h_bpos, h_cgBK_pos, sizeof(h_cgBK_pos));
+    memcpy(h_bpos + CG_KEY_NGRP * 64, h_cgBP_pos, sizeof(h_cgBP_pos));
     if (!(up(h_cgS_pk, sizeof(h_cgS_pk), &pk) && up(h_cg_t_c, sizeof(h_cg_t_c), &cf32) &&
           up(h_cg_row_start, sizeof(h_cg_row_start), &rs) && up(h_cgG_pk, sizeof(h_cgG_pk), &gpk) &&
           up(h_cgT_c, sizeof(h_cgT_c), &gc) && up(h_cgT_start, sizeof(h_cgT_start), &gs) &&
           up(h_cg_row_perm, sizeof(h_cg_row_perm), &rp) && up(h_cg_key_perm, sizeof(h_cg_key_perm), &kp) &&
-          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp) && up(h_cg_rowS, sizeof(h_cg_rowS), &rw)))
+          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp) && up(h_cg_rowS, sizeof(h_cg_rowS), &rw) &&
+          up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq)))
       MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
     g_cgtab[dev] = {(const unsigned*)pk, (const float*)cf32, (const unsigned short*)rs, (const unsigned*)gpk,
                     (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned int*)rw,
-                    (const unsigned short*)kp, (const unsigned short*)pp};
+                    (const unsigned short*)kp, (const unsigned short*)pp, (const uint2*)bt, (const unsigned int*)bq};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
@@ -307,7 +318,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
         d.col = w.dcol[k];
         d.nparts = 5;
       }
-      hipLaunchKernelGGL(k_dot, dim3((TE * 50 + 255) / 256), dim3(256), 0, s, TE, w.L, A, d);
+      const int n_dot = (TE * 50 + 255) / 256;
+      hipLaunchKernelGGL(k_dot, dim3(n_dot + TA), dim3(256), 0, s, TE, w.L, A, d, w.Acm[k], TA, n_dot);
     }
     LAUNCH_CHECK();
     if (k == 0) side_join(s);  // radial columns of every level are in place
@@ -357,8 +369,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
       ProfScope prof(s, "k_catbuild_mfma");
-      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64 * CGM_WAVES), 0, s, w.L, A, E, w.Y, cd,
-                         g_cgtab[cur_device()], TA);
+      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
+                         cd, g_cgtab[cur_device()], TA, TE);
     }
     LAUNCH_CHECK();
     GemmG ga[5];

@@ -121,3 +121,85 @@ def test_generated_kernel_tables_match_sympy():
             hits = [t for t in range(row_start[r], row_start[r + 1])
                     if (i1s[t], i2s[t]) in ((i, partner), (partner, i)) and abs(cs[t] - ic[q]) < 1e-12]
             assert hits, (i, q)
+
+
+def _slice_offsets():
+    """(l, block position, m) -> position of the AGGREGATE entry inside one channel's slice of an atom's concatenated
+    rows: for l, for m: [ag blocks | in | sq blocks] (2 nblk_l + 1 complex per row), as cg_mfma.inc lays it out"""
+    nblk = [len(_blocks(l)) for l in range(MAXL + 1)]
+    out, base = {}, 0
+    for l in range(MAXL + 1):
+        w = 2 * nblk[l] + 1
+        for mi in range(2 * l + 1):
+            for bp in range(nblk[l]):
+                out[(l, bp, mi - l)] = (base + mi * w + bp, nblk[l] + 1)
+        base += (2 * l + 1) * w
+    assert base == 775
+    return out
+
+
+def test_resolved_adjoint_tables_match_sympy():
+    """The lane-major {offset, coefficient} tables the backward CG kernel keeps in LDS (gen_tables.py `resolved`):
+    every entry (x, y) of the adjoint moment matrix must gather exactly the terms
+    dG[x][y] = sum_l <l1 m1 l2 m2 | l m1+m2> d ag[l, block(l1, l2), m1+m2] (aggregate block) and the symmetrised
+    S[x][y] = dP[x][y] + dP[y][x] (power block, diagonal counted twice), each pair of entries exactly once."""
+    T = _tables()
+    text = open(os.path.join(ROOT, 'molgym_amd', 'csrc', 'cg_tables.inc')).read()
+    gmax = {k: [int(v) for v in re.search(r'#define %s \{([^}]*)\}' % k, text).group(1).split(',')]
+            for k in ('CG_KEY_GMAX', 'CG_PAIR_GMAX')}
+    off_of = _slice_offsets()
+    LD = 52
+    dump = int(re.search(r'#define CG_POS_DUMP (\d+)', text).group(1))
+    assert dump >= 26 * LD  # outside the matrix (and its zero row)
+
+    def want_key(x, y, power):
+        (l1, m1), (l2, m2) = _lm(x), _lm(y)
+        out = {}
+        for l in range(abs(l1 - l2), min(l1 + l2, MAXL) + 1):
+            if abs(m1 + m2) > l:
+                continue
+            c = exact(l1, m1, l2, m2, l, m1 + m2)
+            if abs(c) > 1e-14:
+                o, dist = off_of[(l, _blocks(l).index((l1, l2)), m1 + m2)]
+                out[o + (dist if power else 0)] = out.get(o + (dist if power else 0), 0.0) + c
+        return out
+
+    def lanes(prefix, gm):
+        off, cf, pos = T[prefix + '_off'].astype(int), T[prefix + '_c'], T[prefix + '_pos'].astype(np.int64)
+        assert len(off) == len(cf) == 64 * sum(gm) and len(pos) == 64 * len(gm)
+        slot = 0
+        for g, n in enumerate(gm):
+            for t in range(64):
+                got = {}
+                for j in range(n):
+                    o, c = off[(slot + j) * 64 + t], cf[(slot + j) * 64 + t]
+                    if c != 0.0:
+                        got[o] = got.get(o, 0.0) + c
+                yield int(pos[g * 64 + t]), got
+            slot += n
+
+    seen = set()
+    for pos, got in lanes('h_cgBK', gmax['CG_KEY_GMAX']):
+        if pos == dump:
+            assert not got
+            continue
+        x, y = pos // LD, (pos % LD) // 2
+        assert pos == x * LD + 2 * y and (x, y) not in seen and x < 25 and y < 25
+        seen.add((x, y))
+        want = want_key(x, y, False)
+        assert set(got) == set(want) and all(abs(got[o] - want[o]) < 1e-7 for o in want), (x, y)
+    assert len(seen) == 625
+    seen = set()
+    for pos, got in lanes('h_cgBP', gmax['CG_PAIR_GMAX']):
+        if pos == (dump | (dump << 16)):
+            assert not got
+            continue
+        p1, p2 = pos & 0xffff, pos >> 16
+        x, y = p1 // LD, (p1 % LD) // 2
+        assert p1 == x * LD + 2 * y and p2 == y * LD + 2 * x and x <= y and (x, y) not in seen
+        seen.add((x, y))
+        want = want_key(x, y, True)
+        for o, c in want_key(y, x, True).items():
+            want[o] = want.get(o, 0.0) + c   # x == y: the same terms again, i.e. doubled
+        assert set(got) == set(want) and all(abs(got[o] - want[o]) < 1e-7 for o in want), (x, y)
+    assert len(seen) == 325
