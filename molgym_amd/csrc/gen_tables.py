@@ -196,15 +196,38 @@ def main():
                 row_info.append((l, row_start[r], row_start[r + 1] - row_start[r], pos, nblk[l] + 1))
                 r += 1
     rowS, rowS_gmax, rowS_part = [], [], []
+    # RESOLVED lane-major table of the forward projection (k_catbuild_mfma): slot (g, j) of lane t = {float index of the moment
+    # G[i1][i2] (= i1 * 52 + 2 * i2; the power moment A[i1] A[i2] sits at the same index of a second matrix), coefficient};
+    # fw_pos: where the lane's two results go inside the LDS stage of its part, aggregate | power << 16 (part-relative slice
+    # positions), CG_FW_DUMP for padding lanes
+    FW_DUMP = 511
+    fw_off, fw_c, fw_pos = [], [], []
+    part_base = [0, 251, 496]
     for part, ls in enumerate(((0, 1, 2), (3, ), (4, ))):
         rows = sorted((ri for ri in row_info if ri[0] in ls), key=lambda ri: -ri[2])
         for g in range(0, len(rows), 64):
             grp = rows[g:g + 64]
-            rowS_gmax.append(max(ri[2] for ri in grp))
+            gm = max(ri[2] for ri in grp)
+            rowS_gmax.append(gm)
             rowS_part.append(part)
             for ri in grp:
                 rowS.append(ri[1] | (ri[2] << 11) | (ri[3] << 15) | (ri[4] << 25))
             rowS += [1023 << 15] * (64 - len(grp))
+            for j in range(gm):
+                for t in range(64):
+                    if t < len(grp) and j < grp[t][2]:
+                        i1, i2, c = terms[grp[t][1] + j]
+                        fw_off.append(i1 * LD + 2 * i2)
+                        fw_c.append(c)
+                    else:
+                        fw_off.append(0)
+                        fw_c.append(0.0)
+            for t in range(64):
+                if t < len(grp):
+                    pos = grp[t][3] - part_base[part]
+                    fw_pos.append(pos | ((pos + grp[t][4]) << 16))
+                else:
+                    fw_pos.append(FW_DUMP | (FW_DUMP << 16))
 
     out = []
     w = out.append
@@ -243,6 +266,11 @@ def main():
     w(f'static const unsigned short h_cg_pair_perm[{len(pair_perm)}] = {{' + ', '.join(map(str, pair_perm)) + '};')
     w('#define CG_PAIR_GMAX {' + ', '.join(map(str, pair_gmax)) + '}')
     w(f'#define CG_PAIR_NGRP {len(pair_gmax)}')
+    w(f'#define CG_FW_SLOTS {sum(rowS_gmax)}')
+    w(f'#define CG_FW_DUMP {FW_DUMP}')
+    w(f'static const unsigned short h_cgFW_off[{len(fw_off)}] = {{' + ', '.join(map(str, fw_off)) + '};')
+    w(f'static const float h_cgFW_c[{len(fw_c)}] = {{' + ', '.join(f'{c:.9e}f' for c in fw_c) + '};')
+    w(f'static const unsigned int h_cgFW_pos[{len(fw_pos)}] = {{' + ', '.join(map(str, fw_pos)) + '};')
     w(f'#define CG_POS_DUMP {POS_DUMP}')
     w(f'#define CG_BK_SLOTS {sum(key_gmax)}')
     w(f'#define CG_BP_SLOTS {sum(pair_gmax)}')

@@ -35,7 +35,9 @@ static int ensure_tables() {
     auto up = [](const void* src, size_t bytes, void** dst) {
       return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw, *bt, *bq;
+    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw, *bt, *bq, *ft, *fq;
+    static uint2 h_ftab[CG_FW_SLOTS * 64];
+    for (int i = 0; i < CG_FW_SLOTS * 64; ++i) { h_ftab[i].x = h_cgFW_off[i]; memcpy(&h_ftab[i].y, &h_cgFW_c[i], 4); }
     // resolved adjoint tables: {offset, coefficient bits} word pairs, aggregate block then power block
     static uint2 h_btab[(CG_BK_SLOTS + CG_BP_SLOTS) * 64];
     static unsigned int h_bpos[(CG_KEY_NGRP + CG_PAIR_NGRP) * 64];
@@ -51,11 +53,13 @@ static int ensure_tables() {
           up(h_cgT_c, sizeof(h_cgT_c), &gc) && up(h_cgT_start, sizeof(h_cgT_start), &gs) &&
           up(h_cg_row_perm, sizeof(h_cg_row_perm), &rp) && up(h_cg_key_perm, sizeof(h_cg_key_perm), &kp) &&
           up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp) && up(h_cg_rowS, sizeof(h_cg_rowS), &rw) &&
-          up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq)))
+          up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq) && up(h_ftab, sizeof(h_ftab), &ft) &&
+          up(h_cgFW_pos, sizeof(h_cgFW_pos), &fq)))
       MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
     g_cgtab[dev] = {(const unsigned*)pk, (const float*)cf32, (const unsigned short*)rs, (const unsigned*)gpk,
                     (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned int*)rw,
-                    (const unsigned short*)kp, (const unsigned short*)pp, (const uint2*)bt, (const unsigned int*)bq};
+                    (const unsigned short*)kp, (const unsigned short*)pp, (const uint2*)bt, (const unsigned int*)bq,
+                    (const uint2*)ft, (const unsigned int*)fq};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
@@ -369,7 +373,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
       ProfScope prof(s, "k_catbuild_mfma");
-      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid(TA * CH)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
+      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
                          cd, g_cgtab[cur_device()], TA, TE);
     }
     LAUNCH_CHECK();

@@ -203,3 +203,48 @@ def test_resolved_adjoint_tables_match_sympy():
             want[o] = want.get(o, 0.0) + c   # x == y: the same terms again, i.e. doubled
         assert set(got) == set(want) and all(abs(got[o] - want[o]) < 1e-7 for o in want), (x, y)
     assert len(seen) == 325
+
+
+def test_resolved_forward_table_matches_sympy():
+    """The lane-major {moment index, coefficient} table of the forward projection: every output row (l, block, m) of the
+    concatenated channels gathers exactly sum_{m1 + m2 = m} <l1 m1 l2 m2 | l m> G[(l1, m1)][(l2, m2)], lands at its slice
+    position (aggregate) / nblk_l + 1 further (power), every row exactly once."""
+    T = _tables()
+    text = open(os.path.join(ROOT, 'molgym_amd', 'csrc', 'cg_tables.inc')).read()
+    gmax = [int(v) for v in re.search(r'#define CG_ROWS_GMAX \{([^}]*)\}', text).group(1).split(',')]
+    part = [int(v) for v in re.search(r'#define CG_ROWS_PART \{([^}]*)\}', text).group(1).split(',')]
+    dump = int(re.search(r'#define CG_FW_DUMP (\d+)', text).group(1))
+    off, cf, pos = T['h_cgFW_off'].astype(int), T['h_cgFW_c'], T['h_cgFW_pos'].astype(np.int64)
+    assert len(off) == len(cf) == 64 * sum(gmax) and len(pos) == 64 * len(gmax)
+    LD, part_base = 52, [0, 251, 496]
+    where = {}   # slice position of the aggregate entry -> (l, block position, m, nblk + 1)
+    for (l, bp, m), (o, dist) in _slice_offsets().items():
+        where[o] = (l, bp, m, dist)
+    seen, slot = set(), 0
+    for g, n in enumerate(gmax):
+        for t in range(64):
+            p = int(pos[g * 64 + t])
+            got = {}
+            for j in range(n):
+                o, c = off[(slot + j) * 64 + t], cf[(slot + j) * 64 + t]
+                if c != 0.0:
+                    got[o] = got.get(o, 0.0) + c
+            if p == (dump | (dump << 16)):
+                assert not got
+                continue
+            ag = (p & 0xffff) + part_base[part[g]]
+            l, bp, m, dist = where[ag]
+            assert (p >> 16) + part_base[part[g]] == ag + dist and ag not in seen
+            assert (l <= 2 and part[g] == 0) or l - 2 == part[g]
+            seen.add(ag)
+            l1, l2 = _blocks(l)[bp]
+            want = {}
+            for m1 in range(-l1, l1 + 1):
+                m2 = m - m1
+                if abs(m2) <= l2:
+                    c = exact(l1, m1, l2, m2, l, m)
+                    if abs(c) > 1e-14:
+                        want[(l1 * l1 + m1 + l1) * LD + 2 * (l2 * l2 + m2 + l2)] = c
+            assert set(got) == set(want) and all(abs(got[o] - want[o]) < 1e-7 for o in want), (l, bp, m)
+        slot += n
+    assert len(seen) == 375
