@@ -94,6 +94,13 @@ int mg_cov_forward(const mg_cov_cfg* cfg, const float* theta, const float* pos, 
 int mg_cov_sample(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
                   const float* bags, const float* leb, uint64_t seed, int32_t mode, void* ws, size_t ws_bytes,
                   float* actions_out, float* out, void* stream);
+/* The same with the random stream of row b keyed by sample_base + sample_stride * b instead of b: a rollout stepped in
+ * GROUPS of environments (molgym_amd/ppo.py::_rollout_pipelined overlaps one group's host-side reward,
+ * reward.py:36-55, with the other group's policy evaluation; env_container.py:11-74 step_async / step_wait) then draws for
+ * every environment what ONE launch over all of them draws.  mg_cov_sample == base 0, stride 1.          */
+int mg_cov_sample_ids(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
+                      const float* bags, const float* leb, uint64_t seed, int32_t sample_base, int32_t sample_stride,
+                      int32_t mode, void* ws, size_t ws_bytes, float* actions_out, float* out, void* stream);
 /* gout [3][B] f32: dL/dlogp, dL/dent, dL/dv.  grad_theta += dL/dtheta.                 */
 int mg_cov_backward(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges,
                     const float* bags, const float* actions, const float* leb, void* ws, size_t ws_bytes,

@@ -46,3 +46,40 @@ def search_path(*sub):
 
 
 __path__ = search_path()
+
+
+def _init_distributed_from_env():
+    """`python -m torch.distributed.run --nproc-per-node N scripts/run.py ...` with the script UNCHANGED: the reference's
+    scripts know nothing about process groups (scripts/run.py:23-60) and `util.init_device` hands every rank plain
+    `torch.device('cuda')` (tools/util.py:186-194).  When the launcher's environment is there (RANK / WORLD_SIZE /
+    LOCAL_RANK, world > 1) and nobody initialised torch.distributed yet, this import does it: the rank's GPU becomes the
+    current device (so that 'cuda' IS this rank's GPU), the process group comes up on RCCL ('nccl'; 'gloo' without a GPU),
+    and `molgym.ppo.batch_ppo` is told to treat the script's arguments as the GLOBAL configuration (it keeps this rank's
+    share of the environments and of the steps, offsets the rollout RNG streams by rank; the model, built from the common
+    seed before, is identical everywhere).  MOLGYM_NO_DIST=1 switches this off; MOLGYM_DIST_BACKEND overrides the backend."""
+    if os.environ.get('MOLGYM_NO_DIST') == '1':
+        return
+    try:
+        world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '-1'))
+    except ValueError:
+        return
+    if world <= 1 or rank < 0:
+        return
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or dist.is_initialized():
+        return
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    use_gpu = torch.cuda.is_available()
+    backend = os.environ.get('MOLGYM_DIST_BACKEND') or ('nccl' if use_gpu else 'gloo')
+    if use_gpu:
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+    else:
+        dist.init_process_group(backend)
+    from molgym_amd import ppo as _ppo
+    _ppo.DP_SHARD_GLOBAL_CONFIG = True
+
+
+_init_distributed_from_env()

@@ -41,6 +41,8 @@ SYMBOLS = {
                                           C.POINTER(C.c_int64)]),
     'mg_cov_forward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P]),
     'mg_cov_sample': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, _P, C.c_size_t, _P, _P, _P]),
+    'mg_cov_sample_ids': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
+                                    _P, _P, _P]),
     'mg_cov_backward': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     'mg_canvas_append': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P, _P]),
     'mg_adam_step': (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

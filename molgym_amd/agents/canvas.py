@@ -41,6 +41,7 @@ class DeviceCanvas:
         self.natoms = natoms.copy()  # host mirrors: size the kernels' ragged lists / spot foreign changes, no round trip
         self.bags_host = bags.astype(np.int64)
         self._zs_c = (C.c_int32 * len(self.zs))(*self.zs)
+        self.last_placed = None  # (mask, float64 positions) of the atoms the last committed step_canvas placed
 
     def sync(self, indices: Sequence[int], observations: List) -> None:
         """overwrite the rows `indices` with freshly parsed observations (environments that were reset)"""
@@ -67,13 +68,24 @@ class DeviceCanvas:
         self.natoms_dev[idx] = buf[:, 4 * N + Z].to(self.natoms_dev.dtype)
         self.natoms[np.asarray(indices)] = natoms
         self.bags_host[np.asarray(indices)] = bags.astype(np.int64)
+        if self.last_placed is not None:
+            self.last_placed[0][np.asarray(indices)] = False
 
     def stale_rows(self, observations: List, terminals) -> np.ndarray:
-        """environments whose canvas on the device no longer describes `observations`: the ones that were reset, and any
-        whose bag differs from the mirror (an environment that refills its bag, environment.py:186-196) -- a cheap
-        host-side test (B short tuples), no parse"""
+        """environments whose canvas on the device no longer describes `observations`: the ones that were reset, any whose
+        bag differs from the mirror (an environment that refills its bag, environment.py:186-196), and any whose newest
+        atom is not the one the last `step_canvas` placed -- the device canvases assume APPEND-ONLY environments (the
+        reference's: environment.py:95-117 appends exactly the agent's atom or terminates); an environment that relaxes or
+        edits its canvas is caught here and simply re-uploaded every step.  Host-side tests on B short tuples, no parse."""
         bags = np.array([obs[1] for obs in observations], dtype=np.int64)
-        return np.nonzero(np.asarray(terminals, dtype=bool) | (bags != self.bags_host).any(axis=1))[0]
+        stale = np.asarray(terminals, dtype=bool) | (bags != self.bags_host).any(axis=1)
+        if self.last_placed is not None:
+            placed, positions = self.last_placed
+            for b in np.nonzero(placed & ~stale)[0]:
+                item = observations[b][0][int(self.natoms[b]) - 1]
+                if self.zs[item[0]] == 0 or tuple(item[1]) != tuple(positions[b]):
+                    stale[b] = True
+        return np.nonzero(stale)[0]
 
     def append(self, actions: torch.Tensor, commit: bool = True) -> torch.Tensor:
         """place the atoms of the action rows (E, 6) on the canvases (commit) or only compute where they would go;

@@ -161,6 +161,7 @@ class CovariantAC(FlatThetaAgent):
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_last_ws'] = None
+        state.pop('_last_cfg', None)
         state.pop('_ws_cache', None)
         return state
 
@@ -302,8 +303,18 @@ class CovariantAC(FlatThetaAgent):
             _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos),
                                                  _ptr(batch.charges), _ptr(batch.bags), _ptr(batch.actions),
                                                  _ptr(self.leb), _ptr(ws), ws.numel(), _ptr(out), self._s()))
-        self._last_ws = ws
+        self._last_ws, self._last_cfg = ws, batch.cfg
         return out
+
+    def check_inputs(self) -> None:
+        """Surface the list-build flags of the LAST forward (mg_cov_check: canvases whose atoms are not compacted to the
+        front, TA / TE that do not match the charges) as RuntimeError.  It reads 16 bytes back, i.e. synchronises: ppo.train
+        calls it once per call, right after the first epoch's own device -> host copy."""
+        cfg, ws = getattr(self, '_last_cfg', None), self._last_ws
+        if cfg is None or ws is None:
+            return
+        with self._guard():
+            _lib.check(_lib.lib().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
@@ -355,15 +366,24 @@ class CovariantAC(FlatThetaAgent):
         return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
                 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
 
+    @staticmethod
+    def draw_seed() -> int:
+        """one sampling seed from the torch RNG (follows torch.manual_seed, util.set_seeds)"""
+        return int(torch.randint(0, 2**62, (1, )).item())
+
     # -- persistent device canvases (rollouts): no per-step parse, the drawn atom is appended on the device -------------
     def make_canvas(self, observations: List[ObservationType]) -> 'DeviceCanvas':
         from .canvas import DeviceCanvas
         return DeviceCanvas(self, observations)
 
-    def step_canvas(self, canvas: 'DeviceCanvas', commit: bool = True) -> Dict[str, Any]:
+    def step_canvas(self, canvas: 'DeviceCanvas', commit: bool = True, seed: Optional[int] = None,
+                    sample_ids: Tuple[int, int] = (0, 1)) -> Dict[str, Any]:
         """step(observations) of the rollout on resident canvases: same sampling kernels, same return dict; with
         `commit` the drawn atoms are then placed on the canvases in HBM (the host hands `actions` to the environments
-        and calls `canvas.sync` for the ones that were reset or changed in any other way)."""
+        and calls `canvas.sync` for the ones that were reset or changed in any other way).
+        `seed` / `sample_ids = (base, stride)`: the random stream of canvas row b is keyed by (seed, base + stride * b) --
+        a rollout stepped in groups of environments passes the step's common seed and the group's environment ids, and
+        every environment draws what one call over all of them would draw (ppo._rollout_pipelined)."""
         B = canvas.E
         natoms_before = canvas.natoms.copy()
         cfg = self._make_cfg(B, natoms_before)
@@ -371,12 +391,14 @@ class CovariantAC(FlatThetaAgent):
         ws = self._workspace(cfg)
         out = torch.empty(3, B, dtype=torch.float32, device=dev)
         acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
-        seed = int(torch.randint(0, 2**62, (1, )).item())
+        if seed is None:
+            seed = self.draw_seed()
         mode = 1 if self.training else 2
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
-                                                _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws),
-                                                ws.numel(), _ptr(acts), _ptr(out), self._s()))
+            _lib.check(_lib.lib().mg_cov_sample_ids(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
+                                                    _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), int(sample_ids[0]),
+                                                    int(sample_ids[1]), mode, _ptr(ws), ws.numel(), _ptr(acts), _ptr(out),
+                                                    self._s()))
         self._last_ws = ws
         dists = self._dists(cfg, ws, canvas.bags.clone())
         newpos = canvas.append(acts, commit)
@@ -386,6 +408,7 @@ class CovariantAC(FlatThetaAgent):
             placed = (np.asarray(self.zs)[elements] != 0) & (natoms_before < cfg.N)
             canvas.natoms = natoms_before + placed.astype(np.int32)
             canvas.bags_host[np.nonzero(placed)[0], elements[placed]] -= 1
+            canvas.last_placed = (placed.copy(), host_p.astype(np.float64))
         actions = [(int(e), (float(p[0]), float(p[1]), float(p[2]))) for e, p in zip(elements, host_p)]
         return {'actions': actions, 'a': acts, 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
 

@@ -18,7 +18,7 @@ import torch
 from .. import _lib, layout
 from ..spaces import ActionSpace, ObservationSpace, ObservationType
 from .base import FlatThetaAgent
-from .covariant import _ptr, _stream, parse_observations_host
+from .covariant import _ptr, _stream, compact_canvases, observation_arrays
 
 
 def place_new_atoms(pos: np.ndarray, natoms: np.ndarray, focus: np.ndarray, distance, angle, dihedral) -> np.ndarray:
@@ -158,16 +158,11 @@ class SchNetAC(FlatThetaAgent):
 
     def _parse(self, observations: List[ObservationType]):
         """What make_batch needs from the observations alone (the rollout step parses once for its five passes)."""
-        N, B = self.num_atoms, len(observations)
-        pos32, charges, bags, natoms = parse_observations_host(observations, self.zs, N)
-        # exact float64 positions for the z-matrix step, as the reference (ase.Atoms positions are float64)
-        pos64 = np.zeros((B, N, 3))
-        for b, (canvas, _) in enumerate(observations):
-            k = 0
-            for label, xyz in canvas:
-                if self.zs[label] != 0:
-                    pos64[b, k] = xyz
-                    k += 1
+        # exact float64 positions for the z-matrix step, as the reference (ase.Atoms positions are float64); vectorised, and
+        # a `ParsedObservations` (arrays already) is taken as is
+        labels, xyz, bags = observation_arrays(observations, self.zs, self.num_atoms)
+        pos64, charges, natoms = compact_canvases(labels, xyz, self.zs)
+        bags = bags.astype(np.float32)
         return charges, bags, natoms, pos64
 
     def _placements(self, parsed, actions: np.ndarray):

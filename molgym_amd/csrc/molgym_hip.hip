@@ -195,7 +195,7 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scra
 }
 
 struct SampleCtx {
-  uint64_t seed;
+  RngKey seed;
   int mode;
 };
 // actions is read-only unless smp != nullptr, in which case the sub-actions are drawn in place as the heads run.
@@ -501,13 +501,20 @@ extern "C" int mg_cov_forward(const mg_cov_cfg* c, const float* theta, const flo
                           nullptr);
 }
 
+extern "C" int mg_cov_sample_ids(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
+                                 const float* bags, const float* leb, uint64_t seed, int32_t sample_base, int32_t sample_stride,
+                                 int32_t mode, void* ws, size_t ws_bytes, float* actions_out, float* out, void* stream) {
+  if (mode != SAMPLE_TRAIN && mode != SAMPLE_EVAL) MG_FAIL(MG_EINVAL, "mode must be 1 (sample) or 2 (argmax)");
+  if (sample_base < 0 || sample_stride < 1) MG_FAIL(MG_EINVAL, "sample ids base %d stride %d", sample_base, sample_stride);
+  HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
+  SampleCtx smp = {{seed, sample_base, sample_stride}, mode};
+  return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
+}
+
 extern "C" int mg_cov_sample(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
                              const float* bags, const float* leb, uint64_t seed, int32_t mode, void* ws,
                              size_t ws_bytes, float* actions_out, float* out, void* stream) {
-  if (mode != SAMPLE_TRAIN && mode != SAMPLE_EVAL) MG_FAIL(MG_EINVAL, "mode must be 1 (sample) or 2 (argmax)");
-  HIP_CHECK(hipMemsetAsync(actions_out, 0, (size_t)c->B * 6 * sizeof(float), (hipStream_t)stream));
-  SampleCtx smp = {seed, mode};
-  return cov_forward_impl(c, theta, pos, charges, bags, actions_out, leb, ws, ws_bytes, out, stream, &smp);
+  return mg_cov_sample_ids(c, theta, pos, charges, bags, leb, seed, 0, 1, mode, ws, ws_bytes, actions_out, out, stream);
 }
 
 extern "C" int mg_canvas_append(int32_t B, int32_t N, int32_t Z, const int32_t* zs_host, const float* actions, double* pos64,

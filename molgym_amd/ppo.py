@@ -12,14 +12,21 @@ copy of 7 doubles.  An agent without that device path (anything with just `step`
 autograd, mini-batch by mini-batch, like the reference.  Both ways share one sharding / reduction code path.
 
 Data parallel (new; the reference is single-process).  When torch.distributed is initialised:
-  * rollout: every rank steps its OWN environments; `gather_rollout` standardises the advantages over all ranks
-    (buffer.py:104-110 needs the global mean / std: two tiny float64 all-reduces) and all-gathers the rollout, so
-    every rank holds the same `data`, ordered by rank -- exactly the buffer a single process driving all the
-    environments would have merged;
-  * update: rank 0's permutation is broadcast each epoch, every rank takes its contiguous slice of every
-    mini-batch with gradient scale B_local / B_global (an empty slice contributes zero), and the flat gradient is
-    summed ONCE per epoch (one ~0.75 MB RCCL all-reduce) before norm / clip / step, so all ranks take identical
-    Adam steps; the 6 loss statistics ride in one 48-byte float64 all-reduce.
+  * rollout: every rank steps its OWN environments; `gather_rollout` all-gathers the rollout as ONE float64 matrix per
+    rank (observations as arrays, `ParsedObservations`; no pickling of Python tuples) in rank order and standardises the
+    advantages over the merged buffer (buffer.py:104-110) -- exactly the `data` a single process driving all the
+    environments would have built;
+  * update: rank 0's permutation is broadcast each epoch (an int64 tensor); WHOLE mini-batches are dealt round-robin to the
+    ranks (the reference accumulates the gradient over all mini-batches of an epoch and steps once, ppo.py:117-146, so
+    which rank evaluates which mini-batch changes nothing, and B_local stays at the mini-batch size instead of
+    mini_batch / world), the leftover mini-batches of an epoch -- fewer than `world` -- are sliced contiguously with
+    gradient scale B_local / B_global (an empty slice contributes zero); the flat gradient is summed ONCE per epoch
+    (one ~0.75 MB RCCL all-reduce) before norm / clip / step, so all ranks take identical Adam steps; the 6 loss
+    statistics ride in one 48-byte float64 all-reduce.
+  * `torchrun scripts/run.py` UNCHANGED: the `molgym` shim initialises the process group (molgym/__init__.py) and sets
+    `DP_SHARD_GLOBAL_CONFIG`; `batch_ppo` then treats `envs` / `num_steps_per_iter` as the GLOBAL configuration every rank
+    built identically, keeps this rank's share of the environments and offsets the rollout RNG streams by rank (the
+    model was built before, from the same seed on every rank).
 """
 import logging
 import time
@@ -29,8 +36,11 @@ import numpy as np
 import torch
 
 from .buffer import DynamicPPOBuffer, PPOBufferContainer
+from .observations import ParsedObservations
 
 KEYS = ('policy_loss', 'entropy_loss', 'vf_loss', 'total_loss', 'approx_kl', 'clip_fraction')
+# set by the `molgym` shim when IT initialised torch.distributed for an unchanged reference script (see batch_ppo)
+DP_SHARD_GLOBAL_CONFIG = False
 
 
 def _dist():
@@ -80,7 +90,9 @@ def get_batch_generator(indices: np.ndarray, batch_size: int) -> Iterator[np.nda
 def collect_data_batch(data: Dict[str, Sequence], indices: np.ndarray) -> Dict[str, Sequence]:
     batch: Dict[str, Sequence] = {}
     for key, value in data.items():
-        if isinstance(value, np.ndarray):
+        if isinstance(value, ParsedObservations):
+            batch[key] = value.take(indices)
+        elif isinstance(value, np.ndarray):
             batch[key] = value[indices]
         elif torch.is_tensor(value):  # get_data(device=...) hands over float64 device tensors
             batch[key] = value[torch.as_tensor(np.asarray(indices, dtype=np.int64), device=value.device)]
@@ -194,13 +206,31 @@ class _AutogradRunner:
         pass
 
 
+def _comm_device(dist) -> torch.device:
+    return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+
 def _epoch_batches(num_samples: int, mini_batch_size: int, dist, rank: int) -> List[np.ndarray]:
     batches = list(get_batch_generator(np.arange(num_samples), mini_batch_size))  # every rank advances its numpy RNG
-    if dist is not None:  # ... but rank 0's permutation is the one everybody uses
-        box = [batches if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        batches = box[0]
+    if dist is not None and num_samples > 0:  # ... but rank 0's permutation is the one everybody uses
+        perm = torch.from_numpy(np.concatenate(batches).astype(np.int64)).to(_comm_device(dist))
+        dist.broadcast(perm, src=0)
+        flat, sizes = perm.cpu().numpy(), [len(b) for b in batches]  # (the batch sizes follow from the two counts alone)
+        batches = [flat[lo:lo + n] for lo, n in zip(np.concatenate([[0], np.cumsum(sizes)[:-1]]), sizes)]
     return batches
+
+
+def shard_epoch(batches: List[np.ndarray], rank: int, world: int) -> List[Tuple[np.ndarray, float]]:
+    """This rank's work of one epoch: [(sample indices, share of their mini-batch)].  The first floor(M / world) * world
+    mini-batches are dealt WHOLE, round-robin (share 1); the remaining < world ones are sliced contiguously over the ranks
+    (share = B_local / B_global; possibly empty).  Summed over the ranks every mini-batch is covered exactly once."""
+    whole = (len(batches) // world) * world
+    work = [(b, 1.0) for k, b in enumerate(batches[:whole]) if k % world == rank]
+    for b in batches[whole:]:
+        n = len(b)
+        lo, hi = (rank * n) // world, ((rank + 1) * n) // world
+        work.append((b[lo:hi], (hi - lo) / n))
+    return work
 
 
 def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_ratio: float, target_kl: float,
@@ -217,17 +247,18 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
     num_epochs = 0
     for i in range(max_num_steps):
         optimizer.zero_grad()
-        slices = []  # (this rank's slice, its share) of every mini-batch of the epoch
-        for batch_indices in _epoch_batches(num_samples, mini_batch_size, dist, rank):
-            n_glob = len(batch_indices)
-            lo, hi = (rank * n_glob) // world, ((rank + 1) * n_glob) // world
-            slices.append((batch_indices[lo:hi], (hi - lo) / n_glob))
+        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank)
+        slices = shard_epoch(batches, rank, world)  # (this rank's sample indices, their share of the mini-batch)
         runner.set_epoch([sl for sl, _ in slices])
         runner.begin_epoch()
         batch_stats = [runner.run(mb_index, sl, share) for mb_index, (sl, share) in enumerate(slices)]
         runner.end_epoch()
-        # mean of mini-batch means (ppo.py:92-95)
-        stats = batch_stats[0] if len(batch_stats) == 1 else torch.stack(batch_stats).mean(dim=0)
+        # mean of mini-batch means (ppo.py:92-95): every entry is (share x the mean over its samples); over all ranks the
+        # entries of one mini-batch add up to its mean
+        if batch_stats:
+            stats = torch.stack(batch_stats).sum(dim=0) / len(batches)
+        else:
+            stats = torch.zeros(6, dtype=torch.float64, device=runner.dev)
         if dist is not None:
             dist.all_reduce(stats)
             for p in ac.parameters():
@@ -240,6 +271,8 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
             host = torch.cat([stats, ac.grad_norm_clip(gradient_clip).double()]).tolist()  # the epoch's only device -> host copy
             loss_info = dict(zip(KEYS, host[:6]))
             loss_info['grad_norm'] = host[6]
+            if i == 0 and hasattr(ac, 'check_inputs'):
+                ac.check_inputs()  # the stream is idle right here: inconsistent inputs raise instead of training on garbage
         else:
             loss_info = dict(zip(KEYS, stats.tolist()))
             loss_info['grad_norm'] = compute_gradient_norm(ac.parameters())
@@ -337,14 +370,35 @@ def _rollout_pipelined(ac, envs, container, num_steps, pipeline):
     num_iters = num_steps // envs.get_size()
     groups = envs.groups(pipeline)
     obs = [envs.reset(g) for g in groups]
+    # one set of device-resident canvases PER GROUP (CovariantAC on the GPU): a group's policy evaluation is then a sampling
+    # launch on resident arrays -- no parse, no upload -- while the other group's environments step on the host
+    canvases = [ac.make_canvas(o) if _use_canvas(ac) else None for o in obs]
     pending = [None] * len(groups)  # (ticket, host predictions) of the step in flight per group
+    # Sampling: the serial rollout draws ONE seed per step and row b of the batch reads the random stream (seed, b).  Here the
+    # groups of one step share that step's seed and key their rows by ENVIRONMENT id (groups are g, g + k, g + 2k, ...: an
+    # affine map), so every environment sees the same draws as in the serial rollout and the buffers come out identical.
+    affine = all(list(g) == list(range(g[0], g[0] + len(groups) * len(g), len(groups))) for g in groups) and \
+        sorted(g[0] for g in groups) == list(range(len(groups)))
+    seeds: List[int] = []
 
-    def launch(k):
-        predictions = ac.step(obs[k])
+    def seed_of(step):  # seeds are drawn in step order, one per step, like the serial loop (num_iters + 1 in total)
+        while len(seeds) <= step:
+            seeds.append(ac.draw_seed())
+        return seeds[step]
+
+    def evaluate(k, step, commit=True):
+        if canvases[k] is not None:
+            if affine:
+                return ac.step_canvas(canvases[k], commit=commit, seed=seed_of(step), sample_ids=(groups[k][0], len(groups)))
+            return ac.step_canvas(canvases[k], commit=commit)
+        return ac.step(obs[k])
+
+    def launch(k, step):
+        predictions = evaluate(k, step)
         pending[k] = (envs.step_async(predictions['actions'], groups[k]), _host_predictions(predictions))
 
     for k in range(len(groups)):
-        launch(k)  # group k+1's policy evaluation overlaps group k's environment step
+        launch(k, 0)  # group k+1's policy evaluation overlaps group k's environment step
     for it in range(num_iters):
         for k, g in enumerate(groups):
             ticket, (a, v, logp) = pending[k]
@@ -352,10 +406,13 @@ def _rollout_pipelined(ac, envs, container, num_steps, pipeline):
             container.store(observations=obs[k], actions=a, rewards=rewards, next_observations=next_obs,
                             terminals=terminals, values=v, logps=logp, env_indices=g)
             obs[k] = envs.reset_if_terminal(next_obs, terminals, g)
+            if canvases[k] is not None:
+                stale = canvases[k].stale_rows(obs[k], terminals)
+                canvases[k].sync(stale, [obs[k][i] for i in stale])
             if it < num_iters - 1:
-                launch(k)
+                launch(k, it + 1)
             else:
-                _, v, _ = _host_predictions(ac.step(obs[k]))
+                _, v, _ = _host_predictions(evaluate(k, num_iters, commit=False))
                 container.finish_paths(v, env_indices=g)
 
 
@@ -368,29 +425,90 @@ def compute_buffer_stats(buffer: DynamicPPOBuffer) -> Dict[str, float]:
     }
 
 
+def all_gather_rows(mat: np.ndarray) -> np.ndarray:
+    """Rows of a float64 matrix of every rank, concatenated in rank order (ranks may hold different numbers of rows): one
+    all-gather of the counts, one of the zero-padded matrices."""
+    dist, rank, world = _dist()
+    assert dist is not None and mat.ndim == 2
+    dev = _comm_device(dist)
+    count = torch.tensor([mat.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    counts = [int(c.item()) for c in counts]
+    padded = torch.zeros(max(max(counts), 1), mat.shape[1], dtype=torch.float64, device=dev)
+    padded[:mat.shape[0]] = torch.from_numpy(np.ascontiguousarray(mat, dtype=np.float64)).to(dev)
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    return np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, counts)], axis=0)
+
+
 def gather_rollout(buffer: DynamicPPOBuffer) -> dict:
-    """`buffer.get_data()` of the rollout of ALL ranks (every rank stepped its own environments): advantages
-    standardised with the global population mean / std (buffer.py:104-110; two float64 all-reduces: [sum, n], then
-    [sum of squared deviations] -- the same two-pass form numpy uses), rollout all-gathered in rank order.  Without
-    torch.distributed this is `buffer.get_data()`."""
+    """`buffer.get_data()` of the rollout of ALL ranks (every rank stepped its own environments), merged in rank order --
+    the buffer one process driving all the environments would have built -- with the advantages standardised over the
+    merged buffer (buffer.py:104-110).  The exchange is tensor collectives on arrays: observations travel as the
+    [labels | positions | bag] matrix of `ParsedObservations` next to act / ret / adv / logp / val, ONE padded float64
+    all-gather per iteration (the earlier all_gather_object pickled every observation tuple of the rollout on every rank).
+    `data['obs']` is a `ParsedObservations` (a Sequence of the reference's tuples; the HIP agents' parsers take its arrays
+    directly); `data['val']` (extra key, unused by `train`) lets rank 0 log buffer statistics of the whole rollout.
+    Without torch.distributed this is `buffer.get_data()`."""
     dist, rank, world = _dist()
     if dist is None:
         return buffer.get_data()
     assert buffer.is_finished()
-    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
-    adv = np.array(buffer.adv_buf, dtype=np.float64)
-    first = torch.tensor([adv.sum(), float(len(adv))], dtype=torch.float64, device=dev)
-    dist.all_reduce(first)
-    mean = first[0].item() / first[1].item()
-    second = torch.tensor([np.square(adv - mean).sum()], dtype=torch.float64, device=dev)
-    dist.all_reduce(second)
-    std = np.sqrt(second.item() / first[1].item())
-    local = dict(obs=buffer.obs_buf, act=np.array(buffer.act_buf), ret=np.array(buffer.ret_buf),
-                 adv=(adv - mean) / std, logp=np.array(buffer.logp_buf))
-    parts: List[Optional[dict]] = [None] * world
-    dist.all_gather_object(parts, local)
-    return dict(obs=[o for p in parts for o in p['obs']],
-                **{k: np.concatenate([p[k] for p in parts]) for k in ('act', 'ret', 'adv', 'logp')})
+    T = len(buffer.obs_buf)
+    shape = torch.tensor([0, 0, 0], dtype=torch.int64, device=_comm_device(dist))  # canvas size, labels, action width
+    if T:
+        obs = ParsedObservations.from_list(buffer.obs_buf)
+        act = np.asarray(buffer.act_buf, dtype=np.float64).reshape(T, -1)
+        shape = torch.tensor([obs.canvas_size, obs.num_labels, act.shape[1]], dtype=torch.int64, device=shape.device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)  # a rank with an empty buffer still has to size its (empty) matrix
+    N, Z, A = (int(v) for v in shape.tolist())
+    if T:
+        local = np.concatenate([obs.to_matrix(), act, np.asarray(buffer.ret_buf, dtype=np.float64)[:, None],
+                                np.asarray(buffer.adv_buf, dtype=np.float64)[:, None],
+                                np.asarray(buffer.logp_buf, dtype=np.float64)[:, None],
+                                np.asarray(buffer.val_buf, dtype=np.float64)[:, None]], axis=1)
+    else:
+        local = np.zeros((0, 4 * N + Z + A + 4), dtype=np.float64)
+    full = all_gather_rows(local)
+    k = 4 * N + Z
+    adv = full[:, k + A + 1]
+    return dict(obs=ParsedObservations.from_matrix(full[:, :k], N, Z), act=full[:, k:k + A], ret=full[:, k + A],
+                adv=(adv - np.mean(adv)) / np.std(adv), logp=full[:, k + A + 2], val=full[:, k + A + 3])
+
+
+def _global_rollout_info(container: PPOBufferContainer, info: dict) -> dict:
+    """Episode statistics of the rollouts of ALL ranks (rank 0 logs and saves them): episodic returns / lengths gathered
+    as one small matrix."""
+    dist, rank, world = _dist()
+    if dist is None:
+        return info
+    rows = np.stack([np.asarray(container.episodic_returns, dtype=np.float64),
+                     np.asarray(container.episode_lengths, dtype=np.float64)], axis=1).reshape(-1, 2)
+    full = all_gather_rows(rows)
+    out = dict(info)
+    if len(full):
+        out.update(return_mean=np.mean(full[:, 0]).item(), return_std=np.std(full[:, 0]).item(),
+                   episode_length_mean=np.mean(full[:, 1]).item(), episode_length_std=np.std(full[:, 1]).item())
+    return out
+
+
+def _shard_global_config(envs, num_steps_per_iter: int, rank: int, world: int):
+    """`torchrun scripts/run.py` unchanged: every rank built ALL `num_envs` environments and was told the GLOBAL
+    `num_steps_per_iter`.  Keep this rank's contiguous share of the environments and of the steps (so the job as a
+    whole is the single-process configuration), and move the rollout RNG streams apart (numpy: environments /
+    stochastic bags; torch: action sampling) -- the model exists already, built from the same seed on every rank."""
+    size = envs.get_size()
+    if size % world or num_steps_per_iter % world or not hasattr(envs, 'environments'):
+        raise RuntimeError(f'data-parallel launch of an unchanged script: num_envs ({size}) and num_steps_per_iter '
+                           f'({num_steps_per_iter}) must be multiples of the world size ({world}), and the training '
+                           'container must expose `.environments`')
+    per = size // world
+    envs.environments = envs.environments[rank * per:(rank + 1) * per]
+    base = int(np.random.randint(2**31 - world))  # the same draw on every rank (same seed so far)
+    np.random.seed(base + rank)
+    torch.manual_seed(base + rank)
+    return envs, num_steps_per_iter // world
 
 
 def batch_ppo(
@@ -424,6 +542,8 @@ def batch_ppo(
     Under torch.distributed `envs` are THIS rank's environments and `num_steps_per_iter` counts this rank's steps;
     rank 0 alone evaluates, logs and saves."""
     dist, rank, world = _dist()
+    if dist is not None and DP_SHARD_GLOBAL_CONFIG:
+        envs, num_steps_per_iter = _shard_global_config(envs, num_steps_per_iter, rank, world)
     total_num_steps = start_num_steps
     num_iterations = (max_num_steps - total_num_steps) // (num_steps_per_iter * world)
     logging.info('Starting PPO')
@@ -435,15 +555,23 @@ def batch_ppo(
         logging.info(f'Training rollout: return={train_rollout["return_mean"]:.3f} '
                      f'({train_rollout["return_std"]:.1f}), episode length={train_rollout["episode_length_mean"]:.1f}')
         train_buffer = train_container.merge()
+        data = None
+        if dist is not None:  # rank 0 logs the rollout of ALL ranks
+            data = gather_rollout(train_buffer)
+            train_rollout = _global_rollout_info(train_container, train_rollout)
         if info_saver and rank == 0:
             train_rollout['total_num_steps'] = total_num_steps
-            train_rollout.update(compute_buffer_stats(train_buffer))
+            if data is not None:
+                train_rollout.update(value_mean=np.mean(data['val']).item(), value_std=np.std(data['val']).item(),
+                                     logp_mean=np.mean(data['logp']).item(), logp_std=np.std(data['logp']).item())
+            else:
+                train_rollout.update(compute_buffer_stats(train_buffer))
             info_saver.save(train_rollout, name='train')
-        if rollout_saver and save_train_rollout and rank == 0:
-            rollout_saver.save(train_buffer, num_steps=total_num_steps, info='train')
+        if rollout_saver and save_train_rollout:  # every rank saves ITS buffer; ranks > 0 tag the file
+            rollout_saver.save(train_buffer, num_steps=total_num_steps, info='train' if rank == 0 else f'train-rank{rank}')
 
-        if dist is not None:
-            data = gather_rollout(train_buffer)
+        if data is not None:
+            pass
         elif hasattr(ac, 'prepare_rollout') and next(ac.parameters()).device.type == 'cuda':
             data = train_buffer.get_data(device=next(ac.parameters()).device)  # GAE + standardisation on the device
         else:

@@ -35,10 +35,47 @@ def make_pair(cfg_name='cfg2', seed=0, beta='cfg', device='cuda:0', dtype=torch.
     return ac, ref, cfg
 
 
-def rel_err(got, want, floor=1.0):
+def rel_err(got, want, floor=1e-2, abs_tol=1e-6, tol=1e-5):
+    """Worst elementwise error in units where `< tol` (1e-5 by default) means: TRUE relative error below `tol` wherever
+    |want| >= floor (1e-2), absolute error below `abs_tol` (1e-6) for the smaller entries -- north_star's "1e-5 relative
+    on logits / values / loss" without pretending that a float32 value of 1e-4 carries five digits through a three-level
+    Clebsch-Gordan network.  (Rounds 1-2 divided by max(|want|, 1): an ABSOLUTE 1e-5 below one.)"""
     got = torch.as_tensor(got).double().cpu()
     want = torch.as_tensor(want).double().cpu()
-    return ((got - want).abs() / want.abs().clamp(min=floor)).max().item()
+    diff = (got - want).abs()
+    big = want.abs() >= floor
+    err = torch.where(big, diff / want.abs().clamp(min=floor), diff * (tol / abs_tol))
+    return err.max().item() if err.numel() else 0.0
+
+
+def abs1_err(got, want):
+    """|got - want| / max(|want|, 1): relative above one, ABSOLUTE below.  For quantities that are sums of O(1) float32 terms
+    but may themselves be small (a single head's log-probability, outputs re-evaluated by a second kernel path): there a
+    float32 path cannot hold a relative bound, and the tests say so by using this form."""
+    got = torch.as_tensor(got).double().cpu()
+    want = torch.as_tensor(want).double().cpu()
+    return ((got - want).abs() / want.abs().clamp(min=1.0)).max().item()
+
+
+def grad_report(got_flat, want_named, slot_table):
+    """per parameter slot: (max |err| / slot max, slot max, worst TRUE relative error over the entries above 1 % of the
+    slot max) -- the first is the headline gradient tolerance ("2e-4 of the slot maximum"); the second check keeps a wrong
+    small-magnitude block from hiding inside a slot with a few large entries"""
+    report = {}
+    for name, (off, shape) in slot_table.items():
+        n = int(np.prod(shape))
+        gw = want_named[name].grad.reshape(-1).double().cpu()
+        gg = got_flat[off:off + n].double().cpu()
+        scale = gw.abs().max().item()
+        sel = gw.abs() >= 0.01 * scale
+        elem = ((gg - gw).abs()[sel] / gw.abs()[sel]).max().item() if scale > 0 and bool(sel.any()) else 0.0
+        report[name] = ((gg - gw).abs().max().item() / max(scale, 1e-12), scale, elem)
+    return report
+
+
+def assert_grads(report, tol=2e-4, tol_elem=1e-2):
+    bad = {k: v for k, v in report.items() if v[1] >= 1e-10 and not (v[0] < tol and v[2] < tol_elem)}
+    assert not bad, f'gradient mismatch (err / slot max, slot max, worst relative error of the entries above 1 %): {bad}'
 
 
 def compact_vec(parts, atom_mask):

@@ -3,9 +3,13 @@
 * `train`, autograd branch (any AbstractActorCritic: compute_loss + backward) -- TinyAC;
 * `train`, DEVICE branch (agents with prepare_rollout / ppo_minibatch, i.e. the code the HIP agents run: loss_scale,
   device-side statistics, empty slices as zeros) -- TinyDeviceAC implements that interface with torch on the CPU;
+* WHOLE mini-batches dealt round-robin to the ranks (32 samples = 4 mini-batches of 8: no slicing at all), mixed with a
+  sliced leftover (23 samples: two whole + a remainder of 7), and the partition itself (`shard_epoch`);
 * a remainder mini-batch smaller than the world size (one rank's slice is EMPTY);
-* rollout sharding: every rank holds its own environments' buffer, `gather_rollout` standardises the advantages
-  globally and all-gathers; the result must equal `get_data()` of the merged single-process buffer.
+* rollout sharding: every rank holds its own environments' buffer, `gather_rollout` all-gathers ONE float64 matrix per rank
+  (observations as arrays) and standardises the advantages over the merged buffer; the result must equal `get_data()` of
+  the merged single-process buffer;
+* the `molgym` shim initialising the process group for an UNCHANGED single-process script under torch.distributed.run.
 The HIP kernels themselves need a GPU; what is under test here is the sharding / reduction logic around them."""
 import os
 import socket
@@ -111,8 +115,34 @@ def _check_train(tmp_path, kind, n):
         assert abs(a['infos'][k] - b['infos'][k]) < 1e-6 * max(1.0, abs(a['infos'][k])), k
 
 
+def test_shard_epoch_covers_every_minibatch_exactly_once():
+    rng = np.random.default_rng(0)
+    for n, mb, world in ((140, 140, 8), (1400, 140, 8), (23, 8, 2), (17, 8, 2), (64, 8, 3), (5, 8, 4)):
+        batches = list(ppo.get_batch_generator(np.arange(n), mb))
+        seen, shares = [], [0.0] * len(batches)
+        for rank in range(world):
+            work = ppo.shard_epoch(batches, rank, world)
+            whole = [w for w in work if w[1] == 1.0 and len(w[0]) == mb]
+            if len(batches) >= world:  # B_local stays at the mini-batch size wherever a whole one is available
+                assert len(whole) >= len(batches) // world
+            for idx, share in work:
+                seen += list(idx)
+                k = [i for i, b in enumerate(batches) if len(idx) == 0 or idx[0] in b]
+                if len(idx):
+                    shares[k[0]] += share
+                    assert abs(share - len(idx) / len(batches[k[0]])) < 1e-12
+        assert sorted(seen) == list(range(n)) and all(abs(s - 1.0) < 1e-12 for s in shares)
+    del rng
+
+
 def test_world2_equals_world1(tmp_path):
-    _check_train(tmp_path, 'autograd', 23)  # 23: uneven slices and a remainder mini-batch of 7
+    _check_train(tmp_path, 'autograd', 23)  # 23: two whole mini-batches (one per rank) and a sliced remainder of 7
+
+
+def test_whole_minibatch_sharding_world2_equals_world1(tmp_path):
+    """32 samples = 4 mini-batches of 8: every rank evaluates two WHOLE mini-batches, nothing is sliced"""
+    _check_train(tmp_path, 'autograd', 32)
+    _check_train(tmp_path, 'device', 32)
 
 
 def test_world2_equals_world1_device_branch(tmp_path):
@@ -159,7 +189,38 @@ def test_rollout_sharding_matches_single_process(tmp_path):
     _run_gather(0, 1, 0, single)
     mp.spawn(_run_gather, args=(2, _free_port(), double), nprocs=2, join=True)
     a, b = torch.load(single, weights_only=False), torch.load(double, weights_only=False)
-    assert a['obs'] == b['obs'] and len(a['obs']) == 24
+    from molgym_amd.observations import ParsedObservations
+    assert isinstance(b['obs'], ParsedObservations) and len(a['obs']) == len(b['obs']) == 24
+    assert np.array_equal(ParsedObservations.from_list(a['obs']).to_matrix(), b['obs'].to_matrix())  # bit for bit
+    assert b['obs'][5] == a['obs'][5]  # ... and an element reads back as the reference's tuple
     for k in ('act', 'ret', 'adv', 'logp'):
         assert np.allclose(a[k], b[k], rtol=1e-12, atol=1e-12), k
     assert abs(a['adv'].mean()) < 1e-12 and abs(a['adv'].std() - 1) < 1e-12
+
+
+# ---- an unchanged single-process script under torch.distributed.run ---------------------------------------------------
+def test_shim_initialises_the_process_group_for_an_unchanged_script(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 script.py` where the script only imports `molgym` and calls
+    `molgym.ppo.batch_ppo` like scripts/run.py does (it knows nothing about ranks): the shim brings up the process group
+    (gloo here), every rank keeps half of the 4 environments and half of the steps, the rollout RNG streams differ by
+    rank, the replicas stay identical, and rank 0's log covers the rollout of both ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'shim')
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), MOLGYM_DIST_BACKEND='gloo',
+               OMP_NUM_THREADS='1')
+    env.pop('MOLGYM_REFERENCE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'tests', 'shim_dp_script.py'), out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    r0, r1 = torch.load(out + '.rank0.pt', weights_only=False), torch.load(out + '.rank1.pt', weights_only=False)
+    assert r0['world'] == r1['world'] == 2 and r0['initialised_by_shim'] and r1['initialised_by_shim']
+    assert r0['local_envs'] == r1['local_envs'] == 2                       # 4 environments in the script, 2 per rank
+    assert all(torch.equal(r0['sd'][k], r1['sd'][k]) for k in r0['sd'])     # identical replicas after the updates
+    assert r0['moved']
+    assert r0['rollout_seed_probe'] != r1['rollout_seed_probe']             # decorrelated rollouts
+    # rank 0 logged 16 steps per iteration = the GLOBAL num_steps_per_iter, episode statistics over both ranks
+    assert r0['train_log'] and all(rec['total_num_steps'] % 16 == 0 for rec in r0['train_log'])
+    assert r0['steps_stored_per_iteration'] == r1['steps_stored_per_iteration'] == 8

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from molgym_amd.synthetic import make_batch
-from tests.helpers import make_pair
+from tests.helpers import assert_grads, grad_report, make_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -22,19 +22,11 @@ def _grads(cfg_name, B, seed, beta='cfg', weights=(1.0, 0.3, 0.7)):
     (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
     got = ac.theta.grad.detach().double().cpu()
     want = dict(ref.named_parameters())
-    report = {}
-    for name, (off, shape) in ac.slot_table.items():
-        n = int(np.prod(shape))
-        gw = want[name].grad.reshape(-1)
-        gg = got[off:off + n]
-        scale = gw.abs().max().item()
-        report[name] = ((gg - gw).abs().max().item() / max(scale, 1e-12), scale)
-    return report
+    return grad_report(got, want, ac.slot_table)
 
 
 def _assert_report(report, tol=2e-4):
-    bad = {k: v for k, v in report.items() if not (v[0] < tol or v[1] < 1e-10)}
-    assert not bad, f'gradient mismatch (rel err, scale): {bad}'
+    assert_grads(report, tol)
 
 
 def test_grads_cfg2(built_lib):

@@ -72,3 +72,44 @@ def test_rollout_with_canvas_equals_rollout_with_parsing(built_lib):
     assert a.obs_buf == b.obs_buf and a.term_buf == b.term_buf
     for f in ('act_buf', 'rew_buf', 'val_buf', 'logp_buf', 'adv_buf', 'ret_buf'):
         assert np.array_equal(np.asarray(getattr(a, f), dtype=np.float64), np.asarray(getattr(b, f), dtype=np.float64)), f
+
+
+def test_pipelined_async_rollout_with_group_canvases_equals_serial_and_is_faster(built_lib):
+    """SURVEY 8(f) rank 3 end to end on the GPU (BASELINE configs[4]: reward on the host CPU overlapped with the policy):
+    `AsyncEnvContainer` (worker processes, step_async / step_wait of env_container.py:11-74) + CovariantAC on the HIP path +
+    a reward that burns host CPU like the three PM6 single points of reward.py:36-55.  The pipelined rollout keeps one set
+    of device canvases per group, steps group A's environments on the host while the GPU samples for group B, and --
+    because the groups share each step's seed and key their random streams by environment id -- fills EXACTLY the buffers
+    of the serial canvas rollout over the in-process container, in less wall time."""
+    import time
+
+    from molgym_amd.env_container import AsyncEnvContainer
+    ac, ref, cfg = make_pair('cfg2', seed=43)
+    work = 0.004  # seconds of host CPU per environment step
+    mk = lambda: [FakeMolEnv(7, ZS, (0, 1 + i % 3, 2 + i % 2), work_seconds=work) for i in range(16)]
+    results = {}
+    for kind in ('serial', 'pipelined'):
+        if kind == 'serial':
+            envs = SimpleEnvContainer(mk())
+        else:  # HIP is initialised in this process: the workers must not be forked from it
+            envs = AsyncEnvContainer(mk(), num_workers=4, start_method='forkserver')
+            assert [g[0] for g in envs.groups(2)] == [0, 1]
+        cont = PPOBufferContainer(size=16, gamma=0.99, lam=0.97)
+        ppo.batch_rollout(ac, envs, cont, num_steps=16 * 2)  # warm-up (workspaces, workers)
+        cont = PPOBufferContainer(size=16, gamma=0.99, lam=0.97)
+        envs.reset()
+        torch.manual_seed(11)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ppo.batch_rollout(ac, envs, cont, num_steps=16 * 10, pipeline=2)
+        torch.cuda.synchronize()
+        results[kind] = (cont.merge(), time.perf_counter() - t0)
+        if kind == 'pipelined':
+            envs.close()
+    (a, ta), (b, tb) = results['serial'], results['pipelined']
+    assert a.obs_buf == b.obs_buf and a.term_buf == b.term_buf
+    for f in ('act_buf', 'rew_buf', 'val_buf', 'logp_buf', 'adv_buf', 'ret_buf'):
+        assert np.array_equal(np.asarray(getattr(a, f), dtype=np.float64), np.asarray(getattr(b, f), dtype=np.float64)), f
+    # serial: 16 environments x 4 ms on one core per step; pipelined: 4 worker processes, and the policy evaluation of one
+    # group under the other group's environment step
+    assert tb < 0.75 * ta, (ta, tb)

@@ -94,8 +94,8 @@ def test_dists_match_oracle(built_lib, beta):
            distance_dist.log_prob(act[:, 2]), so3_dist.log_prob(act[:, 3:6])]
     for name, g, w in zip(('focus', 'element', 'distance', 'so3'), got, exp['logps']):
         assert rel_err(g, w) < 2e-5, name
-    assert rel_err(focus_dist.entropy(), exp['ent_parts'][0], floor=1e-3) < 1e-4
-    assert rel_err(element_dist.entropy(), exp['ent_parts'][1], floor=1e-3) < 1e-4
+    assert rel_err(focus_dist.entropy(), exp['ent_parts'][0], floor=1e-3, abs_tol=1e-7, tol=1e-4) < 1e-4
+    assert rel_err(element_dist.entropy(), exp['ent_parts'][1], floor=1e-3, abs_tol=1e-7, tol=1e-4) < 1e-4
     # the four log-probabilities add up to what step() reports
     assert rel_err(sum(got), out['logp']) < 1e-5
     # coefficients = normalize_alms(cond_cov)

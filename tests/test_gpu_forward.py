@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from molgym_amd.synthetic import make_batch
-from tests.helpers import compact_edges, compact_vec, make_pair, rel_err
+from tests.helpers import abs1_err, compact_edges, compact_vec, make_pair, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -78,9 +78,9 @@ def test_head_parts(built_lib):
     parts = ac.workspace_view('parts', ccfg).view(6, B)
     names = ['focus', 'element', 'distance', 'so3']
     for i, n in enumerate(names):
-        assert rel_err(parts[i], exp['logps'][i]) < 1e-5, n
-    assert rel_err(parts[4], exp['ent_parts'][0], floor=1e-3) < 1e-4
-    assert rel_err(parts[5], exp['ent_parts'][1], floor=1e-3) < 1e-4
+        assert abs1_err(parts[i], exp['logps'][i]) < 1e-5, n  # one head's share of logp: sums of O(1) terms, may be ~0
+    assert rel_err(parts[4], exp['ent_parts'][0], floor=1e-3, abs_tol=1e-7, tol=1e-4) < 1e-4
+    assert rel_err(parts[5], exp['ent_parts'][1], floor=1e-3, abs_tol=1e-7, tol=1e-4) < 1e-4
     assert rel_err(ac.workspace_view('logz', ccfg), exp['log_z']) < 1e-5
 
 

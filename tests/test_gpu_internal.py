@@ -6,7 +6,7 @@ import torch
 from molgym_amd.spaces import ActionSpace, ObservationSpace
 from molgym_amd.synthetic import make_batch_internal
 from oracle.internal_ref import SchNetACRef, position_atom
-from tests.helpers import rel_err
+from tests.helpers import abs1_err, rel_err
 
 pytestmark = pytest.mark.gpu
 ZS, N = [0, 9, 16], 7
@@ -109,7 +109,7 @@ def test_rollout_sampling_is_consistent_with_evaluation(built_lib):
             exp = ref.step(obs, a, dtype=torch.float64)
         for k in ('logp', 'ent', 'v'):
             assert torch.equal(out[k], again[k]), k
-            assert rel_err(out[k], exp[k]) < 1e-5, k
+            assert abs1_err(out[k], exp[k]) < 1e-5, k  # drawn actions: values near zero occur (absolute below one)
         assert len(out['actions']) == len(obs)
         idx, pos = out['actions'][1]
         assert 0 <= idx < len(ZS) and len(pos) == 3

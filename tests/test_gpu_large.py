@@ -71,10 +71,13 @@ def test_samples_are_independent_at_full_size(built_lib, name):
     assert (full[:, lo:hi] - part).abs().max().item() < 1e-5 * max(1.0, full.abs().max().item())
 
 
-def test_gradient_is_additive_over_shards_at_full_size(built_lib):
-    """data-parallel contract on cfg3: the gradient of a mini-batch is the sum of its shards'
-    gradients with loss scale B_shard / B"""
-    cfg = CONFIGS['cfg3']
+@pytest.mark.parametrize('name', ['cfg3', 'cfg5'])
+def test_gradient_is_additive_over_shards_at_full_size(built_lib, name):
+    """data-parallel contract at full size: the gradient of a mini-batch is the sum of its shards'
+    gradients with loss scale B_shard / B (cfg5: 2048 samples on canvases of 40 -- the > 512-sample heads backward, the
+    16-byte dW form, the shared DotMatrix block and slice offsets near their 32-bit limit on one side, their smaller-shape
+    siblings on the other)"""
+    cfg = CONFIGS[name]
     ac = _agent(cfg)
     B = cfg['batch']
     data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=7)
@@ -97,11 +100,11 @@ def _run_worker(name, env_extra, path):
     env = dict(os.environ)
     env.update(env_extra)
     subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'large_worker.py'), name, path], check=True, cwd=ROOT,
-                   env=env, timeout=600)
+                   env=env, timeout=1500)
     return np.load(path)
 
 
-@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4', 'cfg5'])
 def test_kernel_families_agree_at_full_size(built_lib, tmp_path, name):
     """MFMA GEMM forms + side stream (default) against the VALU forms on one stream, same inputs and weights: the
     predictions, the loss statistics and the whole gradient vector"""
@@ -114,3 +117,63 @@ def test_kernel_families_agree_at_full_size(built_lib, tmp_path, name):
     assert np.abs(a['pred'] - b['pred']).max() < 1e-5 * max(1.0, np.abs(b['pred']).max())
     assert np.abs(a['stats'] - b['stats']).max() < 1e-5 * max(1.0, np.abs(b['stats']).max())
     assert np.abs(a['grad'] - b['grad']).max() < 2e-4 * np.abs(b['grad']).max()
+
+
+@pytest.mark.parametrize('name', ['cfg4', 'cfg5'])
+def test_directional_derivatives_at_full_size(built_lib, name):
+    """The hand-written backward against the FORWARD kernels at BASELINE's full sizes, where no oracle reaches: for random
+    directions d confined to one parameter slot each, the central difference of L(theta) = sum_b w . (logp, ent, v) along d
+    (two forward passes on the HIP path, outputs summed in float64) must equal <dL/dtheta, d> from mg_cov_backward.  A
+    float32 forward limits the comparison to a few per cent -- enough to expose a wrong block, a missed accumulation or a
+    truncated offset in the size-selected kernels (dw4 / pk / sx, the one-workgroup heads backward), which is its job."""
+    cfg = CONFIGS[name]
+    ac = _agent(cfg, seed=2)
+    B = cfg['batch']
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=9)
+    batch = ac.prepare_batch(data['obs'], data['act'])
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(3, B, generator=g, dtype=torch.float64).cuda() * torch.tensor([[1.0], [0.3], [0.7]], dtype=torch.float64).cuda()
+
+    def loss():
+        with torch.no_grad():
+            return (ac.forward_batch(batch).double() * w).sum().item()
+
+    # analytic gradient: the backward entry point with gout = w
+    import ctypes as C
+    from molgym_amd import _lib
+    out = ac.forward_batch(batch)
+    ws = ac._last_ws
+    grad = torch.zeros_like(ac.theta)
+    gout = w.float().contiguous()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with ac._guard():
+        _lib.check(_lib.lib().mg_cov_backward(C.byref(batch.cfg), p(ac.theta), p(batch.pos), p(batch.charges), p(batch.bags),
+                                              p(batch.actions), p(ac.leb), p(ws), ws.numel(), p(gout), p(grad), ac._s()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(grad).all() and torch.isfinite(out).all()
+    slots = [k for k in ac.slot_table if 'weight' in k and any(t in k for t in (
+        'input_func_atom', 'rad_funcs.0.linear', 'rad_funcs.2.linear', 'edge_levels.0', 'edge_levels.1', 'edge_levels.2',
+        'atom_levels.0', 'atom_levels.1', 'atom_levels.2', 'cg_mix', 'phi_focus', 'phi_trans', 'phi_v', 'phi_d', 'phi_element'))]
+    assert len(slots) >= 8, list(ac.slot_table)[:40]
+    rng = np.random.default_rng(0)
+    picked = [slots[i] for i in rng.choice(len(slots), size=min(10, len(slots)), replace=False)]
+    report = {}
+    for name_ in picked:
+        off, shape = ac.slot_table[name_]
+        n = int(np.prod(shape))
+        d = torch.zeros_like(ac.theta)
+        d[off:off + n] = torch.randn(n, generator=g).cuda()
+        rms = ac.theta[off:off + n].detach().pow(2).mean().sqrt().item()
+        eps = 2e-2 * max(rms, 1e-3)
+        gd = (grad.double() * d.double()).sum().item()
+        with torch.no_grad():
+            ac.theta.add_(d, alpha=eps)
+            lp = loss()
+            ac.theta.add_(d, alpha=-2 * eps)
+            lm = loss()
+            ac.theta.add_(d, alpha=eps)
+        fd = (lp - lm) / (2 * eps)
+        ref = grad[off:off + n].double().norm().item() * d[off:off + n].double().norm().item()
+        report[name_] = (fd, gd, ref)
+    bad = {k: v for k, v in report.items() if not abs(v[0] - v[1]) <= 0.05 * abs(v[1]) + 0.01 * v[2]}
+    assert not bad, f'finite difference vs analytic directional derivative (fd, <g, d>, |g| |d|): {bad}'

@@ -1,13 +1,14 @@
 """Oracle parity at the sizes BASELINE.json names: canvases of 20 and 40 slots with five elements (the neighbour-tile
 loops of the CG kernels, the two-kernel list build and the 64-row GEMM forms only run at n > 16) and the SF6
 mini-batch at its real size of 140 samples (counting sort of the atoms, dW row-chunk classes depend on B / TA).
-Outputs to 1e-5 relative, EVERY parameter gradient to 2e-4 of its per-tensor maximum, against the float64 oracle."""
+Outputs to 1e-5 relative (helpers.rel_err: true relative above 1e-2, absolute 1e-6 below), EVERY parameter gradient to 2e-4 of
+its per-tensor maximum AND to 1e-2 relative on every entry above 1 % of that maximum, against the float64 oracle."""
 import numpy as np
 import pytest
 import torch
 
 from molgym_amd.synthetic import make_batch
-from tests.helpers import make_pair, rel_err
+from tests.helpers import assert_grads, grad_report, make_pair, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -27,15 +28,7 @@ def _compare(cfg_name, B, seed, weights=(1.0, 0.3, 0.7), data=None):
         assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
     got = ac.theta.grad.detach().double().cpu()
     want = dict(ref.named_parameters())
-    bad = {}
-    for name, (off, shape) in ac.slot_table.items():
-        n = int(np.prod(shape))
-        gw = want[name].grad.reshape(-1)
-        scale = gw.abs().max().item()
-        err = (got[off:off + n] - gw).abs().max().item() / max(scale, 1e-12)
-        if not (err < 2e-4 or scale < 1e-10):
-            bad[name] = (err, scale)
-    assert not bad, f'gradient mismatch (rel err, scale): {bad}'
+    assert_grads(grad_report(got, want, ac.slot_table))
     return ac, cfg, data
 
 
