@@ -7,8 +7,11 @@ One step = one pass of the hot path over one synthetic mini-batch (molgym/ppo.py
 ``step(obs, actions)`` -> float64 PPO loss -> backward into ``.grad`` (optimizer step excluded), with
 the parsed mini-batch already resident in HBM.  N > 1: one process per GPU -- launched by torchrun, or by this
 script itself when it is started plainly with --gpus N -- with the flat gradient all-reduced over RCCL inside the
-timed region; `--scaling weak` (default) gives every rank its own mini-batch of the configured size, `--scaling
-strong` shards ONE mini-batch of that size over the ranks.  Rank 0 prints ONE JSON line; `value` follows the contract
+timed region -- ONCE per `--allreduce-every` steps (default 10: the mini-batches of one ppo.train epoch accumulate
+locally and the epoch ends in one all-reduce, ppo.py:117-146 / molgym_amd/ppo.py::train; the line states the cadence);
+`--scaling weak` (default) gives every rank its own mini-batch of the configured size every step, `--scaling strong`
+deals the K WHOLE mini-batches round-robin to the ranks, the way `ppo.train` shards an epoch (total work fixed).
+Rank 0 prints ONE JSON line; `value` follows the contract
 (K steps between synchronisations, max over ranks), `config.median_ms_per_step` is the median over the same K steps
 from per-step HIP events.
 """
@@ -36,9 +39,11 @@ def parse_args():
     p.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                    help='N > 1: weak = the configured mini-batch PER GPU; strong = ONE mini-batch of that size sharded '
                         'over the GPUs (what ppo.train does with a fixed rollout)')
+    p.add_argument('--allreduce-every', type=int, default=10,
+                   help='N > 1: all-reduce the accumulated gradient once per this many steps (one ppo.train epoch)')
     p.add_argument('--inflight', type=int, default=1, help='mini-batches in flight per GPU (independent HIP streams)')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--no-epoch-overlap', action='store_true', help='skip the three-in-flight leg (profiling runs)')
+    p.add_argument('--no-epoch-overlap', action='store_true', help='skip the extra legs (three in flight; host parse inside): profiling runs')
     p.add_argument('--no-build', action='store_true', help='use the library as is (A/B runs with MOLGYM_HIP_LIB)')
     p.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU baseline leg')
     p.add_argument('--force-dist', action='store_true',
@@ -240,31 +245,34 @@ def main():
     if args.scaling == 'weak':   # every rank owns a mini-batch of the configured size
         B = B_glob
         data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=rank)
-    else:                        # strong: ONE mini-batch of the configured size, sharded over the ranks (ppo.train)
-        whole = make_batch(B_glob, cfg['canvas_size'], cfg['zs'], seed=0)
-        lo, hi = (rank * B_glob) // world, ((rank + 1) * B_glob) // world
-        B = hi - lo
-        if B == 0:
-            raise SystemExit(f'strong scaling: {B_glob} samples cannot feed {world} ranks')
-        data = {k: v[lo:hi] for k, v in whole.items()}
-    total_samples = world * B if args.scaling == 'weak' else B_glob
+    else:                        # strong: the K whole mini-batches dealt round-robin to the ranks (ppo.shard_epoch)
+        B = B_glob
+        data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=0)
+    total_samples = world * B if args.scaling == 'weak' else B_glob  # samples per timed step over all ranks
     torch.manual_seed(0)
     ac = CovariantAC(ObservationSpace(cfg['canvas_size'], cfg['zs']), ActionSpace(cfg['zs']),
                      bag_scale=cfg['bag_scale'], beta=cfg['beta'], device=dev, **MODEL_DEFAULTS)
     batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
     ac.theta.grad = torch.zeros_like(ac.theta)
-    loss_scale = B / total_samples  # B_local / B_global: the all-reduced gradient is the global mini-batch mean
+    # weak: a step is `world` mini-batches, the all-reduced gradient their mean; strong: whole mini-batches, scale 1
+    loss_scale = 1.0 / world if args.scaling == 'weak' else 1.0
+    every = max(1, args.allreduce_every)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
-    def step():
+    last_stats = [torch.zeros(6, dtype=torch.float64, device=dev)]
+
+    def step(i=0, last=False):
         if streams is None:
-            ac.theta.grad.zero_()
-            stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
-            if use_dist:
-                dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL/xGMI
-            return stats
+            if not use_dist or i % every == 0:
+                ac.theta.grad.zero_()  # (one GPU: every step, as before; N > 1: once per epoch -- the gradients accumulate)
+            mine = args.scaling == 'weak' or i % world == rank
+            if mine:
+                last_stats[0] = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
+            if use_dist and ((i + 1) % every == 0 or last):
+                dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL / xGMI per epoch
+            return last_stats[0]
         # epoch semantics of ppo.train: gradients of independent mini-batches accumulate; they are issued
         # round-robin on `inflight` streams with their own workspaces
         k = counter[0] % len(streams)
@@ -279,8 +287,8 @@ def main():
             if use_dist:
                 dist.all_reduce(ac.theta.grad)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i, i == args.warmup - 1)
     drain()
     # per-step HIP events on the launch stream (no synchronisation inside the timed region): median step time
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -291,7 +299,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        stats = step()
+        stats = step(i, i == args.steps - 1)
         if streams is None:
             marks[i + 1].record()
     drain()
@@ -341,6 +349,24 @@ def main():
                      'unit': 'samples/s', 'ms_per_step': ep_elapsed / args.steps * 1e3,
                      'note': 'same mini-batch steps issued round-robin on 3 HIP streams (own workspaces), gradients '
                              'accumulating in one buffer: the mini-batches of one ppo.train epoch'}
+    # Third leg (one GPU): the reference's timed region also holds the observation parsing of every mini-batch
+    # (agent.py:165-197 inside step(), ppo.py:124-131): the same K steps with `prepare_batch` (host parse + upload) inside
+    parse_leg = None
+    if streams is None and not use_dist and world == 1 and not args.no_epoch_overlap:
+        for _ in range(2):
+            ac.theta.grad.zero_()
+            ac.ppo_minibatch(ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret']), 0.2, 0.5, 0.01)
+        torch.cuda.synchronize()
+        k_parse = max(1, min(args.steps, 20 if B > 512 else args.steps))
+        t2 = time.perf_counter()
+        for _ in range(k_parse):
+            ac.theta.grad.zero_()
+            ac.ppo_minibatch(ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret']), 0.2, 0.5, 0.01)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t2) / k_parse
+        parse_leg = {'value': B / dt, 'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'steps': k_parse,
+                     'note': 'the same step with the host-side observation parse + upload of the mini-batch inside the '
+                             'timed region (vectorised parser, one packed copy per array)'}
     median_ms = None
     if streams is None:
         median_ms = float(np.median([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]))
@@ -370,10 +396,16 @@ def main():
                        'host_enqueue_ms_per_step': t_issued / args.steps * 1e3,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,
-                       'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world)},
+                       'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world),
+                       # the same with the flops of the REAL atoms only (the kernels skip the padding the dense count includes)
+                       'step_frac_ragged': f_ragged * value / 1e12 / (PEAK_F32_TFLOPS * world),
+                       'allreduce_every_steps': every if use_dist else None},
             'roofline': roof,
             'epoch_overlap': epoch_leg,
+            'with_host_parse': parse_leg,
         }
+        from molgym_amd.profile import step_hbm
+        line['config'].update(step_hbm(args.config, ms))
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v.float().cpu() for k, v in ac.export_state_dict().items()}
             line['cpu_baseline'] = cpu_baseline(args.config, B, rank, sd, args.cpu_seconds)

@@ -101,6 +101,17 @@ def _pmc_traffic(config, name):
     return json.load(open(path)).get(name, {}).get('hbm_bytes_per_launch')
 
 
+def step_hbm(config, ms_per_step):
+    """whole-step HBM traffic from the PMC summary of the same config (`_step` record of tools/pmc_summary.py) against
+    the live step time: {'hbm_bytes_per_step', 'hbm_gbps', 'hbm_frac'} (None without that file)"""
+    path = os.path.join(ROOT, 'profiles', f'pmc_{config}.json')
+    rec = json.load(open(path)).get('_step') if os.path.exists(path) else None
+    if not rec:
+        return {'hbm_bytes_per_step': None, 'hbm_gbps': None, 'hbm_frac': None}
+    gbps = rec['hbm_bytes_per_step'] / (ms_per_step * 1e-3) / 1e9
+    return {'hbm_bytes_per_step': rec['hbm_bytes_per_step'], 'hbm_gbps': gbps, 'hbm_frac': gbps / PEAK_HBM_GBPS}
+
+
 def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
     spans = kernel_spans(ac, batch)
     per_step = {k: v[0] * v[1] for k, v in spans.items()}

@@ -15,7 +15,7 @@ marker=k_prep_weights; if [ "$config" = "cfg2" ]; then marker=k_prep_lists; fi  
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out -o fetch_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/fetch_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out -o write_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/write_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out -o sq_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/sq_$config.log 2>&1
-python tools/pmc_summary.py $out/fetch_${config}_results.db $out/write_${config}_results.db $out/pmc_$config.json $out/sq_${config}_results.db | head -8
+PMC_STEPS=27 python tools/pmc_summary.py $out/fetch_${config}_results.db $out/write_${config}_results.db $out/pmc_$config.json $out/sq_${config}_results.db | head -8
 cp $out/pmc_$config.json profiles/pmc_$config.json
 # (the CPU-baseline leg is the contract's cfg2 line only: one oracle pass at the larger configs takes minutes)
 extra=""; if [ "$config" != "cfg2" ]; then extra="--no-cpu-baseline"; fi

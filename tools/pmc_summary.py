@@ -13,6 +13,7 @@ KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced re
 doubled (an upper bound for narrow accesses; WRITE_SIZE is uncalibrated and taken as is).
 """
 import json
+import os
 import sqlite3
 import sys
 
@@ -47,8 +48,14 @@ def main():
             busy, act = d.get('SQ_VALU_MFMA_BUSY_CYCLES'), d.get('GRBM_GUI_ACTIVE')
             if busy and act and act[1] > 0:
                 rec['mfma_busy_over_gpu_active'] = busy[1] / act[1]
+    # whole step: every kernel's bytes x launches over the steps the profiled command ran (PMC_STEPS: timed + warm-up steps
+    # + the 20 iterations of bench.py's live roofline leg)
+    steps = int(os.environ.get('PMC_STEPS', '0'))
+    if steps > 0:
+        total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values() if 'hbm_bytes_per_launch' in v)
+        out['_step'] = {'steps_in_run': steps, 'hbm_bytes_per_step': total / steps}
     json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
-    top = sorted((kv for kv in out.items() if 'hbm_bytes_per_launch' in kv[1]),
+    top = sorted((kv for kv in out.items() if 'hbm_bytes_per_launch' in kv[1] and 'launches' in kv[1]),
                  key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]
     for k, v in top:
         print(f"{k:40s} launches={v['launches']:5d} bytes/launch={v['hbm_bytes_per_launch'] / 1e6:9.3f} MB")
