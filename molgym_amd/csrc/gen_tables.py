@@ -249,21 +249,13 @@ def main():
     w(f'static const unsigned int h_cgI_pk[{len(inc_flat)}] = {{' + ', '.join(str(e[0] | (e[1] << 16)) for e in inc_flat) + '};')
     w(f'static const float h_cgI_c[{len(inc_flat)}] = {{' + ', '.join(f'{e[2]:.9e}f' for e in inc_flat) + '};')
     w(f'static const unsigned short h_cgT_key[{len(terms)}] = {{' + ', '.join(map(str, t_keys)) + '};')
-    w(f'static const unsigned int h_cgS_pk[{len(terms)}] = {{' + ', '.join(map(str, term_pk)) + '};')
-    w(f'static const unsigned int h_cgG_pk[{len(terms)}] = {{' + ', '.join(map(str, g_pk)) + '};')
     w('static const int h_cg_slice_base[5] = {' + ', '.join(map(str, slice_base)) + '};')
-    w(f'static const unsigned short h_cg_row_perm[{nrows}] = {{' + ', '.join(map(str, row_perm)) + '};')
-    w('#define CG_ROW_GMAX {' + ', '.join(map(str, row_gmax)) + '}')
-    w(f'#define CG_ROW_NGRP {len(row_gmax)}')
-    w(f'static const unsigned int h_cg_rowS[{len(rowS)}] = {{' + ', '.join(map(str, rowS)) + '};')
     w('#define CG_ROWS_GMAX {' + ', '.join(map(str, rowS_gmax)) + '}')
     w('#define CG_ROWS_PART {' + ', '.join(map(str, rowS_part)) + '}')
     w(f'#define CG_ROWS_NGRP {len(rowS_gmax)}')
-    w(f'static const unsigned short h_cg_key_perm[625] = {{' + ', '.join(map(str, key_perm)) + '};')
     w('#define CG_KEY_GMAX {' + ', '.join(map(str, key_gmax)) + '}')
     w(f'#define CG_KEY_NGRP {len(key_gmax)}')
     w(f'#define CG_NPAIRS {len(pair_perm)}')
-    w(f'static const unsigned short h_cg_pair_perm[{len(pair_perm)}] = {{' + ', '.join(map(str, pair_perm)) + '};')
     w('#define CG_PAIR_GMAX {' + ', '.join(map(str, pair_gmax)) + '}')
     w(f'#define CG_PAIR_NGRP {len(pair_gmax)}')
     w(f'#define CG_FW_SLOTS {sum(rowS_gmax)}')

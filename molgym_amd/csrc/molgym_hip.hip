@@ -31,11 +31,11 @@ static int ensure_tables() {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_start), h_cgI_start, sizeof(h_cgI_start)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_pk), h_cgI_pk, sizeof(h_cgI_pk)));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_cgI_c), h_cgI_c, sizeof(h_cgI_c)));
-  {  // the term table the one-wave-per-(atom, channel) CG kernels walk: plain global memory (lane-varying reads)
+  {  // the resolved lane-major tables of the one-wave-per-(atom, channel) CG kernels (copied into LDS once per workgroup)
     auto up = [](const void* src, size_t bytes, void** dst) {
       return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    void *pk, *cf32, *rs, *gpk, *gc, *gs, *rp, *kp, *pp, *rw, *bt, *bq, *ft, *fq;
+    void *bt, *bq, *ft, *fq;
     static uint2 h_ftab[CG_FW_SLOTS * 64];
     for (int i = 0; i < CG_FW_SLOTS * 64; ++i) { h_ftab[i].x = h_cgFW_off[i]; memcpy(&h_ftab[i].y, &h_cgFW_c[i], 4); }
     // resolved adjoint tables: {offset, coefficient bits} word pairs, aggregate block then power block
@@ -48,18 +48,10 @@ static int ensure_tables() {
     }
     memcpy(h_bpos, h_cgBK_pos, sizeof(h_cgBK_pos));
     memcpy(h_bpos + CG_KEY_NGRP * 64, h_cgBP_pos, sizeof(h_cgBP_pos));
-    if (!(up(h_cgS_pk, sizeof(h_cgS_pk), &pk) && up(h_cg_t_c, sizeof(h_cg_t_c), &cf32) &&
-          up(h_cg_row_start, sizeof(h_cg_row_start), &rs) && up(h_cgG_pk, sizeof(h_cgG_pk), &gpk) &&
-          up(h_cgT_c, sizeof(h_cgT_c), &gc) && up(h_cgT_start, sizeof(h_cgT_start), &gs) &&
-          up(h_cg_row_perm, sizeof(h_cg_row_perm), &rp) && up(h_cg_key_perm, sizeof(h_cg_key_perm), &kp) &&
-          up(h_cg_pair_perm, sizeof(h_cg_pair_perm), &pp) && up(h_cg_rowS, sizeof(h_cg_rowS), &rw) &&
-          up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq) && up(h_ftab, sizeof(h_ftab), &ft) &&
+    if (!(up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq) && up(h_ftab, sizeof(h_ftab), &ft) &&
           up(h_cgFW_pos, sizeof(h_cgFW_pos), &fq)))
       MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
-    g_cgtab[dev] = {(const unsigned*)pk, (const float*)cf32, (const unsigned short*)rs, (const unsigned*)gpk,
-                    (const float*)gc, (const unsigned short*)gs, (const unsigned short*)rp, (const unsigned int*)rw,
-                    (const unsigned short*)kp, (const unsigned short*)pp, (const uint2*)bt, (const unsigned int*)bq,
-                    (const uint2*)ft, (const unsigned int*)fq};
+    g_cgtab[dev] = {(const uint2*)bt, (const unsigned int*)bq, (const uint2*)ft, (const unsigned int*)fq};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
