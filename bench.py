@@ -178,6 +178,8 @@ def main_internal(args):
             'config': {'workload': f'configs[0]: SchNet internal-coordinate actor-critic, zs={zs}, canvas_size={N}, '
                                    f'mini_batch={B}, 3B-molecule ragged batch resident in HBM'},
             'roofline': None, 'cpu_baseline': None}
+    from molgym_amd.profile import internal_roofline
+    line['roofline'] = internal_roofline(ac, batch)
     if not args.no_cpu_baseline:
         with tempfile.TemporaryDirectory() as tmp:
             sd_path = os.path.join(tmp, 'sd.pt')
