@@ -56,6 +56,10 @@ typedef struct mg_cov_cfg {
 
 const char* mg_last_error(void);
 int mg_abi_version(void);
+/* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
+ * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
+ * Other values are other builds of the same sources (hipcc -DCH=.. -DCE=..); molgym_amd/_lib.py builds / loads them.   */
+int mg_cov_channels(int32_t* hidden, int32_t* per_element);
 
 /* ---- optional kernel-span timing (measurement only) ------------------------------ */
 /* on != 0: forward/backward bracket their dominant kernels with HIP events recorded on

@@ -32,6 +32,7 @@ _P = C.c_void_p
 SYMBOLS = {
     'mg_last_error': (C.c_char_p, []),
     'mg_abi_version': (C.c_int, []),
+    'mg_cov_channels': (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'mg_profile_enable': (C.c_int, [C.c_int]),
     'mg_profile_report': (C.c_int, [C.c_char_p, C.c_size_t]),
     'mg_cov_num_params': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64)]),
@@ -64,30 +65,75 @@ SYMBOLS = {
 }
 
 _lib = None
+_variants = {}
+DEFAULT_CHANNELS = (10, 4)  # num_channels_hidden, num_channels_per_element of the default build (arg_parser.py:55-60)
 
 
-def lib():
-    """Load (once) and return the library; raises if it is not built."""
+def _bind(path):
+    # torch first: its bundled HIP runtime must be the one this library binds to (loading the library before torch
+    # leaves two runtimes in the process and the second one sees no device)
+    import torch  # noqa: F401
+    handle = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def variant_path(channels):
+    ch, ce = channels
+    return LIB_PATH if tuple(channels) == DEFAULT_CHANNELS else os.path.join(_HERE, f'libmolgym_hip_c{ch}e{ce}.so')
+
+
+def build_variant(channels, force=False):
+    """hipcc build of the same sources for other channel counts (compile-time constants of the kernels): in-tree, next to
+    the default library.  Needs hipcc (present in the ROCm image on both the build container and the GPU box)."""
+    import subprocess
+    path = variant_path(channels)
+    src = os.path.join(_HERE, 'csrc', 'molgym_hip.hip')
+    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(
+            os.path.getmtime(os.path.join(_HERE, 'csrc', f)) for f in os.listdir(os.path.join(_HERE, 'csrc'))
+            if f.endswith(('.hip', '.inc', '.h'))):
+        return path
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        raise RuntimeError(f'num_channels_hidden={channels[0]}, num_channels_per_element={channels[1]} need their own build '
+                           f'of the library and {hipcc} is not there')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', f'-DCH={channels[0]}',
+                           f'-DCE={channels[1]}', src, '-o', path])
+    return path
+
+
+def lib(channels=None):
+    """Load (once) and return the library; raises if it is not built.  `channels` = (num_channels_hidden,
+    num_channels_per_element) selects the build of the Cormorant kernels (None / (10, 4): the default library; anything else
+    is compiled on first use, see build_variant)."""
     global _lib
+    if channels is not None and tuple(channels) != DEFAULT_CHANNELS:
+        key = tuple(int(c) for c in channels)
+        if key not in _variants:
+            if key[0] < 1 or key[0] > 16 or key[1] < 1 or key[1] > 8:
+                raise RuntimeError(f'num_channels_hidden {key[0]} / num_channels_per_element {key[1]} outside what the '
+                                   'kernels were written for (1..16 / 1..8)')
+            handle = _bind(build_variant(key))
+            ch, ce = C.c_int32(), C.c_int32()
+            handle.mg_cov_channels(C.byref(ch), C.byref(ce))
+            if (ch.value, ce.value) != key:
+                raise RuntimeError(f'{variant_path(key)} was built for channels {(ch.value, ce.value)}')
+            _variants[key] = handle
+        return _variants[key]
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                                '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
-        # torch first: its bundled HIP runtime must be the one this library binds to (loading the library before torch
-        # leaves two runtimes in the process and the second one sees no device)
-        import torch  # noqa: F401
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        _lib = handle
+        _lib = _bind(LIB_PATH)
     return _lib
 
 
-def check(rc):
+def check(rc, handle=None):
     if rc != 0:
-        raise RuntimeError(f'molgym_hip error {rc}: {lib().mg_last_error().decode()}')
+        raise RuntimeError(f'molgym_hip error {rc}: {(handle or lib()).mg_last_error().decode()}')
 
 
 def gather_rows(tensors, idx_dev, stream_ptr):

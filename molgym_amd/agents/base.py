@@ -59,6 +59,10 @@ class FlatThetaAgent(AbstractActorCritic):
                 self._slot(k).copy_(sd[k].to(self.theta).reshape(self.slot_table[k][1]))
 
     def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        if args:  # the legacy positional form (destination, prefix, keep_vars) torch.nn.Module still accepts
+            destination = args[0] if destination is None else destination
+            prefix = args[1] if len(args) > 1 and prefix == '' else prefix
+            keep_vars = args[2] if len(args) > 2 and keep_vars is False else keep_vars
         out = OrderedDict() if destination is None else destination
         t = self.theta if keep_vars else self.theta.detach()
         for k in self.slot_table:
@@ -98,10 +102,16 @@ class FlatThetaAgent(AbstractActorCritic):
     def adam_step(self, optimizer) -> bool:
         """optimizer.step() (ppo.py:145) for a plain torch.optim.Adam over the flat theta as ONE HIP launch (mg_adam_step)
         on the optimizer's own state tensors, which are created exactly as torch creates them -- so state_dict(), learning-
-        rate schedulers and a later optimizer.step() see nothing unusual.  Returns False (nothing done) for anything else:
+        rate schedulers (their step counter is advanced here) and a later optimizer.step() see nothing unusual; an
+        optimizer with step hooks is left to optimizer.step().  Returns False (nothing done) for anything else:
         another optimizer class, several parameter groups / tensors, fused / capturable / differentiable variants."""
         from .. import _lib
         if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+            return False
+        # step hooks registered on the optimizer (or globally) must run: leave those cases to optimizer.step()
+        from torch.optim import optimizer as _opt_mod
+        if getattr(optimizer, '_optimizer_step_pre_hooks', None) or getattr(optimizer, '_optimizer_step_post_hooks', None) or \
+                getattr(_opt_mod, '_global_optimizer_pre_hooks', None) or getattr(_opt_mod, '_global_optimizer_post_hooks', None):
             return False
         g = optimizer.param_groups[0]
         p = self.theta
@@ -129,6 +139,11 @@ class FlatThetaAgent(AbstractActorCritic):
                                                ptr(st['max_exp_avg_sq']) if g['amsgrad'] else None, float(g['lr']),
                                                float(beta1), float(beta2), float(g['eps']), float(g['weight_decay']), step,
                                                1 if g.get('maximize') else 0, self._s()))
+        # what a learning-rate scheduler's wrapper of optimizer.step() would have recorded (lr_scheduler.py: `_step_count`,
+        # `_opt_called`; the scheduler warns about "lr_scheduler.step() before optimizer.step()" otherwise)
+        if hasattr(optimizer, '_step_count'):
+            optimizer._step_count += 1
+        optimizer._opt_called = True
         return True
 
     def grad_norm_clip(self, max_norm: float = 0.0) -> torch.Tensor:

@@ -91,15 +91,15 @@ class RolloutOnDevice:
 class _CovStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, theta, ac, cfg, pos, charges, bags, actions):
-        lib = _lib.lib()
+        lib = ac._L()
         nbytes = C.c_size_t()
-        _lib.check(lib.mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        _lib.check(lib.mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)), lib)
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=theta.device)
         out = torch.empty(3, cfg.B, dtype=torch.float32, device=theta.device)
         with torch.cuda.device(theta.device):
             _lib.check(lib.mg_cov_forward(C.byref(cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
                                           _ptr(actions), _ptr(ac.leb), _ptr(ws), nbytes.value, _ptr(out),
-                                          _stream(theta.device)))
+                                          _stream(theta.device)), lib)
         ctx.save_for_backward(theta, pos, charges, bags, actions, ws)
         ctx.cfg, ctx.ac = cfg, ac
         ac._last_ws = ws
@@ -108,13 +108,13 @@ class _CovStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         theta, pos, charges, bags, actions, ws = ctx.saved_tensors
-        lib = _lib.lib()
+        lib = ctx.ac._L()
         grad = torch.zeros_like(theta)
         gout = gout.contiguous()
         with torch.cuda.device(theta.device):
             _lib.check(lib.mg_cov_backward(C.byref(ctx.cfg), _ptr(theta), _ptr(pos), _ptr(charges), _ptr(bags),
                                            _ptr(actions), _ptr(ctx.ac.leb), _ptr(ws), ws.numel(), _ptr(gout),
-                                           _ptr(grad), _stream(theta.device)))
+                                           _ptr(grad), _stream(theta.device)), lib)
         return grad, None, None, None, None, None, None
 
 
@@ -135,10 +135,12 @@ class CovariantAC(FlatThetaAgent):
         device=None,
     ):
         super().__init__(observation_space, action_space)
-        if (maxl, num_cg_levels, num_channels_hidden, num_channels_per_element) != (layout.MAXL, layout.NLEV,
-                                                                                    layout.CH, layout.CE):
-            raise RuntimeError('the gfx950 kernels are built for maxl=4, num_cg_levels=3, num_channels_hidden=10, '
-                               'num_channels_per_element=4 (the reference defaults, arg_parser.py:55-60)')
+        if (maxl, num_cg_levels) != (layout.MAXL, layout.NLEV):
+            raise RuntimeError('the gfx950 kernels are built for maxl=4, num_cg_levels=3 (the reference defaults, '
+                               'arg_parser.py:55-60; every BASELINE config uses them)')
+        # the channel counts are compile-time constants of a library build: the defaults load libmolgym_hip.so, other
+        # values their own build of the same sources (compiled on first use, molgym_amd/_lib.py::build_variant)
+        self._channels = (int(num_channels_hidden), int(num_channels_per_element))
         self.device = torch.device(device) if device is not None else torch.device('cuda')
         self.dtype = torch.float
         self.zs = list(self.observation_space.zs)
@@ -151,11 +153,19 @@ class CovariantAC(FlatThetaAgent):
             raise RuntimeError(f'network_width {network_width}: the HIP heads kernels support multiples of 4 up to 128')
         self.num_gaussians, self.network_width, self.bag_scale = num_gaussians, network_width, bag_scale
         self.num_channels_out = len(self.zs) * num_channels_per_element
-        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians)
+        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)
+        self._L()  # load (build) the library for these channel counts now: a missing toolchain fails here, not mid-rollout
         self.theta = torch.nn.Parameter(self._init_theta(total))
         self.register_buffer('leb', torch.from_numpy(lebedev_table()), persistent=False)
         self._last_ws = None
         self.to(self.device)
+
+    def _chk(self, rc):
+        _lib.check(rc, self._L())
+
+    def _L(self):
+        """the library build for this agent's channel counts"""
+        return _lib.lib(getattr(self, '_channels', None))
 
     # whole-module pickling (ModelIO.save = torch.save(module), tools/model_util.py:82-91): drop the caches
     def __getstate__(self):
@@ -238,7 +248,7 @@ class CovariantAC(FlatThetaAgent):
     def _dists(self, cfg, ws: torch.Tensor, bags: torch.Tensor) -> StepDists:
         block = torch.empty(StepDists.block_floats(cfg), dtype=torch.float32, device=self.theta.device)
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_head_outputs(C.byref(cfg), _ptr(ws), ws.numel(), _ptr(block), self._s()))
+            self._chk(self._L().mg_cov_head_outputs(C.byref(cfg), _ptr(ws), ws.numel(), _ptr(block), self._s()))
         return StepDists(self, cfg, block, bags)
 
     def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
@@ -287,12 +297,15 @@ class CovariantAC(FlatThetaAgent):
 
     def _workspace(self, cfg: _lib.CovCfg, slot: int = 0) -> torch.Tensor:
         nbytes = C.c_size_t()
-        _lib.check(_lib.lib().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        self._chk(self._L().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         cache = self.__dict__.setdefault('_ws_cache', {})
         ws = cache.get(slot)
         if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
             ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
             cache[slot] = ws
+        # the cached block may have been allocated under another stream (rollout: default stream; ppo.train: its own): tell
+        # the caching allocator about THIS use, so that a later replacement is not handed out while kernels still read it
+        ws.record_stream(torch.cuda.current_stream(self.theta.device))
         return ws
 
     def forward_batch(self, batch: 'DeviceBatch', slot: int = 0) -> torch.Tensor:
@@ -300,7 +313,7 @@ class CovariantAC(FlatThetaAgent):
         ws = self._workspace(batch.cfg, slot)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos),
+            self._chk(self._L().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos),
                                                  _ptr(batch.charges), _ptr(batch.bags), _ptr(batch.actions),
                                                  _ptr(self.leb), _ptr(ws), ws.numel(), _ptr(out), self._s()))
         self._last_ws, self._last_cfg = ws, batch.cfg
@@ -314,7 +327,7 @@ class CovariantAC(FlatThetaAgent):
         if cfg is None or ws is None:
             return
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
+            self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
@@ -322,20 +335,20 @@ class CovariantAC(FlatThetaAgent):
         step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED (atomically) into theta.grad.
         Returns the 6 float64 loss statistics (device tensor, no sync).  `slot` selects an independent workspace,
         so the mini-batches of one epoch -- independent given theta -- can be in flight on several HIP streams."""
-        lib = _lib.lib()
+        lib = self._L()
         out = self.forward_batch(batch, slot)
         ws = self._last_ws
         B = batch.cfg.B
         stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
         gout = torch.empty(3, B, dtype=torch.float32, device=self.theta.device)
         with self._guard():
-            _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
+            self._chk(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
                                        vf_coef, entropy_coef, _ptr(stats), _ptr(gout), self._s()))
             if loss_scale != 1.0:
                 gout.mul_(loss_scale)
             if self.theta.grad is None:
                 self.theta.grad = torch.zeros_like(self.theta)
-            _lib.check(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+            self._chk(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
                                            _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
                                            ws.numel(), _ptr(gout), _ptr(self.theta.grad), self._s()))
         return stats
@@ -355,13 +368,13 @@ class CovariantAC(FlatThetaAgent):
         seed = int(torch.randint(0, 2**62, (1, )).item())  # follows torch.manual_seed (util.set_seeds)
         mode = 1 if self.training else 2
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
+            self._chk(self._L().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
                                                 _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(),
                                                 _ptr(acts), _ptr(out), self._s()))
         self._last_ws = ws
         dists = self._dists(cfg, ws, d_bag)
         with self._guard():  # this path synchronises for the actions anyway: surface the list build's error flags
-            _lib.check(_lib.lib().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
+            self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
         host = acts.cpu().numpy()
         return {'actions': [self.to_action_space(a, o) for a, o in zip(host, observations)], 'a': acts,
                 'logp': out[0], 'ent': out[1], 'v': out[2], 'dists': dists}
@@ -395,7 +408,7 @@ class CovariantAC(FlatThetaAgent):
             seed = self.draw_seed()
         mode = 1 if self.training else 2
         with self._guard():
-            _lib.check(_lib.lib().mg_cov_sample_ids(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
+            self._chk(self._L().mg_cov_sample_ids(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
                                                     _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), int(sample_ids[0]),
                                                     int(sample_ids[1]), mode, _ptr(ws), ws.numel(), _ptr(acts), _ptr(out),
                                                     self._s()))
@@ -415,7 +428,7 @@ class CovariantAC(FlatThetaAgent):
     def workspace_view(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:
         """float32 view of a named intermediate of the last forward (tests only)."""
         off, cnt = C.c_int64(), C.c_int64()
-        _lib.check(_lib.lib().mg_cov_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))
+        self._chk(self._L().mg_cov_workspace_lookup(C.byref(cfg), name.encode(), C.byref(off), C.byref(cnt)))
         return self._last_ws.view(torch.float32)[off.value:off.value + cnt.value]
 
     def workspace_view_int(self, name: str, cfg: _lib.CovCfg) -> torch.Tensor:

@@ -5,8 +5,14 @@
 
 #define MAXL 4
 #define NLM 25   // sum_l (2l+1), l <= 4
+// channel counts of the Cormorant encoder: compile-time constants of a library build (tools/arg_parser.py:55-60 defaults);
+// other values are other builds of the same sources (-DCH=.. -DCE=..: molgym_amd/_lib.py builds and loads them on demand)
+#ifndef CH
 #define CH 10    // num_channels_hidden
+#endif
+#ifndef CE
 #define CE 4     // num_channels_per_element
+#endif
 #define NLEV 3   // num_cg_levels
 #define NRADF 32 // radial features per level
 #define NLEB 1730

@@ -96,6 +96,11 @@ extern "C" int mg_profile_report(char* buf, size_t cap) {
   return MG_OK;
 }
 extern "C" int mg_abi_version(void) { return 1; }
+extern "C" int mg_cov_channels(int32_t* hidden, int32_t* per_element) {
+  if (hidden) *hidden = CH;
+  if (per_element) *per_element = CE;
+  return MG_OK;
+}
 
 extern "C" int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params) {
   PLayout P;
@@ -210,7 +215,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int B = c->B, N = c->N, Z = c->Z, TA = c->TA, TE = c->TE, W = c->W;
-  side_policy(TE >= MG_SIDE_MIN_EDGES);
+  side_policy(TE >= MG_SIDE_MIN_EDGES, (hipStream_t)stream);
 #define RC(x) do { rc = (x); if (rc) return rc; } while (0)
   // the derived weight matrices (and the zero of the expanded weight-gradient scratch the backward accumulates
   // into) do not depend on the batch: side stream, beside the list / geometry kernels
@@ -314,7 +319,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
         d.col = w.dcol[k];
         d.nparts = 5;
       }
-      const int n_dot = (TE * 50 + 255) / 256;
+      const int n_dot = (TE * 5 * CH + 255) / 256;
       hipLaunchKernelGGL(k_dot, dim3(n_dot + TA), dim3(256), 0, s, TE, w.L, A, d, w.Acm[k], TA, n_dot);
     }
     LAUNCH_CHECK();

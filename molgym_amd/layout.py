@@ -15,19 +15,22 @@ MAXL, NLEV, CH, CE, NRADF = 4, 3, 10, 4, 32
 NBLK = (5, 12, 16, 17, 15)
 
 
-def edge_cin(k: int, l: int) -> int:
-    return (2 * CH if l == 0 else CH) if k == 0 else 7 * CH
+def edge_cin(k: int, l: int, ch: int = CH) -> int:
+    return (2 * ch if l == 0 else ch) if k == 0 else 7 * ch
 
 
-def atom_tau(k: int, l: int) -> int:
-    return (3 * CH if l == 0 else CH) if k == 0 else CH * (2 * NBLK[l] + 1)
+def atom_tau(k: int, l: int, ch: int = CH) -> int:
+    return (3 * ch if l == 0 else ch) if k == 0 else ch * (2 * NBLK[l] + 1)
 
 
-def mix_tau(l: int) -> int:
-    return CE * (NBLK[l] + 2)
+def mix_tau(l: int, ce: int = CE) -> int:
+    return ce * (NBLK[l] + 2)
 
 
-def slots(num_zs: int, width: int, num_gaussians: int) -> 'OrderedDict[str, Tuple[int, ...]]':
+def slots(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE) -> 'OrderedDict[str, Tuple[int, ...]]':
+    """`ch` / `ce`: num_channels_hidden / num_channels_per_element (arg_parser.py:55-60); the library build has to match
+    (molgym_amd/_lib.py::lib(channels))"""
+    CH, CE = ch, ce  # noqa: N806 (shadow the defaults below)
     co = num_zs * CE
     nlat, nlat_e = (MAXL + 2) * co * 2, (MAXL + 2) * CE * 2
     s: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
@@ -42,13 +45,13 @@ def slots(num_zs: int, width: int, num_gaussians: int) -> 'OrderedDict[str, Tupl
     s['cg_model.input_func_atom.lin.bias'] = (2 * CH, )
     for k in range(NLEV):
         for l in range(MAXL + 1):
-            s[f'cg_model.cormorant_cg.edge_levels.{k}.cat_mix.weights.{l}'] = (CH, edge_cin(k, l), 2)
+            s[f'cg_model.cormorant_cg.edge_levels.{k}.cat_mix.weights.{l}'] = (CH, edge_cin(k, l, CH), 2)
     for k in range(NLEV):
         cout = co if k == NLEV - 1 else CH
         for l in range(MAXL + 1):
-            s[f'cg_model.cormorant_cg.atom_levels.{k}.cat_mix.weights.{l}'] = (cout, atom_tau(k, l), 2)
+            s[f'cg_model.cormorant_cg.atom_levels.{k}.cat_mix.weights.{l}'] = (cout, atom_tau(k, l, CH), 2)
     for l in range(MAXL + 1):
-        s[f'cg_mix.cat_mix.weights.{l}'] = (CE, mix_tau(l), 2)
+        s[f'cg_mix.cat_mix.weights.{l}'] = (CE, mix_tau(l, CE), 2)
     for name, n_in, n_out in (('phi_focus', nlat, 1), ('phi_element', nlat, num_zs),
                               ('phi_d', nlat_e, 2 * num_gaussians), ('phi_trans', nlat, width), ('phi_v', width, 1)):
         s[f'{name}.layers.0.weight'] = (width, n_in)
@@ -59,10 +62,10 @@ def slots(num_zs: int, width: int, num_gaussians: int) -> 'OrderedDict[str, Tupl
     return s
 
 
-def offsets(num_zs: int, width: int, num_gaussians: int):
+def offsets(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE):
     """name -> (offset, shape); also returns the total length."""
     out, off = OrderedDict(), 0
-    for name, shape in slots(num_zs, width, num_gaussians).items():
+    for name, shape in slots(num_zs, width, num_gaussians, ch, ce).items():
         n = 1
         for d in shape:
             n *= d

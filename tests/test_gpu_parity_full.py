@@ -95,3 +95,34 @@ def test_shared_dot_block_layout_vs_oracle(built_lib):
                        env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'deselected' in r.stdout
+
+
+def test_other_channel_counts_vs_oracle(built_lib):
+    """num_channels_hidden = 8, num_channels_per_element = 2 (arg_parser.py:55-60 makes them command-line flags): the channel
+    counts are compile-time constants of a library build, so this agent loads its own build of the same sources
+    (molgym_amd/_lib.py::build_variant; __graft_entry__.build() pre-builds this one) -- outputs and every parameter
+    gradient against the oracle, plus the C-side parameter layout against molgym_amd/layout.py"""
+    import ctypes as C
+    from molgym_amd import _lib, layout
+    ac, ref, cfg = make_pair('cfg2', seed=21, num_channels_hidden=8, num_channels_per_element=2)
+    lib = ac._L()
+    ch, ce = C.c_int32(), C.c_int32()
+    lib.mg_cov_channels(C.byref(ch), C.byref(ce))
+    assert (ch.value, ce.value) == (8, 2) and lib is not _lib.lib()
+    ccfg = ac._make_cfg(1, np.array([1]))
+    n = C.c_int64()
+    _lib.check(lib.mg_cov_num_params(C.byref(ccfg), C.byref(n)), lib)
+    table, total = layout.offsets(len(cfg['zs']), 128, 3, 8, 2)
+    assert n.value == total == ac.theta.numel() and sum(p.numel() for p in ref.parameters()) == total
+    data = make_batch(12, cfg['canvas_size'], cfg['zs'], seed=33)
+    B = len(data['obs'])
+    g = torch.Generator().manual_seed(2)
+    wl, we, wv = (torch.randn(B, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
+    out = ac.step(data['obs'], data['act'])
+    (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
+    assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
