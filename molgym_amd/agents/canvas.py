@@ -61,11 +61,13 @@ class DeviceCanvas:
         buf = torch.from_numpy(packed).to(self.pos64.device)
         idx = buf[:, 4 * N + Z + 1].long()
         p = buf[:, :3 * N].reshape(k, N, 3)
-        self.pos64[idx] = p
-        self.pos32[idx] = p.float()
-        self.charges[idx] = buf[:, 3 * N:4 * N].to(self.charges.dtype)
-        self.bags[idx] = buf[:, 4 * N:4 * N + Z].to(self.bags.dtype)
-        self.natoms_dev[idx] = buf[:, 4 * N + Z].to(self.natoms_dev.dtype)
+        # index_copy_: one launch per array (advanced-indexing assignment is several launches plus index bookkeeping on the
+        # host -- 2.6 ms for 20 environments, six rollout steps' worth)
+        self.pos64.index_copy_(0, idx, p)
+        self.pos32.index_copy_(0, idx, p.float())
+        self.charges.index_copy_(0, idx, buf[:, 3 * N:4 * N].to(self.charges.dtype))
+        self.bags.index_copy_(0, idx, buf[:, 4 * N:4 * N + Z].to(self.bags.dtype))
+        self.natoms_dev.index_copy_(0, idx, buf[:, 4 * N + Z].to(self.natoms_dev.dtype))
         self.natoms[np.asarray(indices)] = natoms
         self.bags_host[np.asarray(indices)] = bags.astype(np.int64)
         if self.last_placed is not None:
