@@ -201,7 +201,7 @@ def main():
     # fw_pos: where the lane's two results go inside the LDS stage of its part, aggregate | power << 16 (part-relative slice
     # positions), CG_FW_DUMP for padding lanes
     FW_DUMP = 511
-    fw_off, fw_c, fw_pos = [], [], []
+    fw_off, fw_c, fw_pos, fw_lbm = [], [], [], []  # fw_lbm: the lane's row as l | block position << 3 | m index << 8 (0xffff: padding)
     part_base = [0, 251, 496]
     for part, ls in enumerate(((0, 1, 2), (3, ), (4, ))):
         rows = sorted((ri for ri in row_info if ri[0] in ls), key=lambda ri: -ri[2])
@@ -226,8 +226,12 @@ def main():
                 if t < len(grp):
                     pos = grp[t][3] - part_base[part]
                     fw_pos.append(pos | ((pos + grp[t][4]) << 16))
+                    l = grp[t][0]
+                    rel = grp[t][3] - slice_base[l]          # = mi * (2 nblk + 1) + bp
+                    fw_lbm.append(l | ((rel % (2 * nblk[l] + 1)) << 3) | ((rel // (2 * nblk[l] + 1)) << 8))
                 else:
                     fw_pos.append(FW_DUMP | (FW_DUMP << 16))
+                    fw_lbm.append(0xffff)
 
     out = []
     w = out.append
@@ -263,6 +267,8 @@ def main():
     w(f'static const unsigned short h_cgFW_off[{len(fw_off)}] = {{' + ', '.join(map(str, fw_off)) + '};')
     w(f'static const float h_cgFW_c[{len(fw_c)}] = {{' + ', '.join(f'{c:.9e}f' for c in fw_c) + '};')
     w(f'static const unsigned int h_cgFW_pos[{len(fw_pos)}] = {{' + ', '.join(map(str, fw_pos)) + '};')
+    w(f'static const unsigned int h_cgFW_lbm[{len(fw_lbm)}] = {{' + ', '.join(map(str, fw_lbm)) + '};')
+    w('#define CG_ROWS_SLOT0 {' + ', '.join(str(sum(rowS_gmax[:g])) for g in range(len(rowS_gmax))) + '}')
     w(f'#define CG_POS_DUMP {POS_DUMP}')
     w(f'#define CG_BK_SLOTS {sum(key_gmax)}')
     w(f'#define CG_BP_SLOTS {sum(pair_gmax)}')

@@ -35,7 +35,7 @@ static int ensure_tables() {
     auto up = [](const void* src, size_t bytes, void** dst) {
       return hipMalloc(dst, bytes) == hipSuccess && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    void *bt, *bq, *ft, *fq;
+    void *bt, *bq, *ft, *fq, *fl;
     static uint2 h_ftab[CG_FW_SLOTS * 64];
     for (int i = 0; i < CG_FW_SLOTS * 64; ++i) { h_ftab[i].x = h_cgFW_off[i]; memcpy(&h_ftab[i].y, &h_cgFW_c[i], 4); }
     // resolved adjoint tables: {offset, coefficient bits} word pairs, aggregate block then power block
@@ -49,9 +49,9 @@ static int ensure_tables() {
     memcpy(h_bpos, h_cgBK_pos, sizeof(h_cgBK_pos));
     memcpy(h_bpos + CG_KEY_NGRP * 64, h_cgBP_pos, sizeof(h_cgBP_pos));
     if (!(up(h_btab, sizeof(h_btab), &bt) && up(h_bpos, sizeof(h_bpos), &bq) && up(h_ftab, sizeof(h_ftab), &ft) &&
-          up(h_cgFW_pos, sizeof(h_cgFW_pos), &fq)))
+          up(h_cgFW_pos, sizeof(h_cgFW_pos), &fq) && up(h_cgFW_lbm, sizeof(h_cgFW_lbm), &fl)))
       MG_FAIL(MG_EHIP, "uploading the CG term tables failed");
-    g_cgtab[dev] = {(const uint2*)bt, (const unsigned int*)bq, (const uint2*)ft, (const unsigned int*)fq};
+    g_cgtab[dev] = {(const uint2*)bt, (const unsigned int*)bq, (const uint2*)ft, (const unsigned int*)fq, (const unsigned int*)fl};
   }
   HIP_CHECK(hipDeviceSynchronize());
   g_tables_ready[dev] = true;
@@ -392,7 +392,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     HeadBuf HB;
     make_head_args(c, P, w, theta, &HD, &HW, &HB);
     ProfScope prof(s, "k_heads_fwd");
-    hipLaunchKernelGGL(k_heads_fwd, dim3(B, 3), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, A3, actions,
+    hipLaunchKernelGGL(k_heads_fwd, dim3(B, 3), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, g_cgtab[cur_device()], A3, actions,
                        bags, leb, out);
     LAUNCH_CHECK();
     return MG_OK;

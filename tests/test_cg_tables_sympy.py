@@ -230,10 +230,12 @@ def test_resolved_forward_table_matches_sympy():
                 if c != 0.0:
                     got[o] = got.get(o, 0.0) + c
             if p == (dump | (dump << 16)):
-                assert not got
+                assert not got and int(T['h_cgFW_lbm'][g * 64 + t]) == 0xffff
                 continue
             ag = (p & 0xffff) + part_base[part[g]]
             l, bp, m, dist = where[ag]
+            lbm = int(T['h_cgFW_lbm'][g * 64 + t])  # the same row as (l, block position, m index): the heads' mixer uses it
+            assert (lbm & 7, (lbm >> 3) & 31, lbm >> 8) == (l, bp, m + l)
             assert (p >> 16) + part_base[part[g]] == ag + dist and ag not in seen
             assert (l <= 2 and part[g] == 0) or l - 2 == part[g]
             seen.add(ag)

@@ -32,8 +32,8 @@ for blk in (0, 8, 801):
     lib.mg_debug_ts(buf, blk)
     ts = np.array(list(buf), dtype=np.int64)
     us = lambda a, b: round((ts[b] - ts[a]) / 100.0, 2)
-    print('block', blk, 'bwd: issue loads', us(32, 48), '| wait + LDS stores', us(48, 49), '| barrier', us(49, 33), '| rebuild power', us(33, 44),
-          '| aD + mfma column', us(44, 45), '| atomics + sync', us(45, 34), '| rebuild aggregate', us(34, 46), '| aD + tile store', us(46, 35),
-          '| tile 0: operands + mfma', us(35, 36), '| P1 epilogue', us(36, 47), '| P2 epilogue', us(47, 37), '| dE', us(37, 38),
+    print('block', blk, 'bwd: issue loads', us(32, 54), '| wait + LDS stores', us(54, 55), '| barrier', us(55, 33), '| rebuild power', us(33, 50),
+          '| aD + mfma column', us(50, 51), '| atomics + sync', us(51, 34), '| rebuild aggregate', us(34, 52), '| aD + tile store', us(52, 35),
+          '| tile 0: operands + mfma', us(35, 36), '| P1 epilogue', us(36, 53), '| P2 epilogue', us(53, 37), '| dE', us(37, 38),
           '| other tiles', us(38, 39), '| total', us(32, 39))
     print('   fwd: loads', us(40, 41), '| mfma', us(41, 42), '| projection', us(42, 43))
