@@ -368,7 +368,7 @@ def main():
         dt = (time.perf_counter() - t2) / k_parse
         parse_leg = {'value': B / dt, 'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'steps': k_parse,
                      'note': 'the same step with the host-side observation parse + upload of the mini-batch inside the '
-                             'timed region (vectorised parser, one packed copy per array)'}
+                             'timed region (vectorised parser, ONE packed host -> device copy for positions / charges / bags / actions)'}
     median_ms = None
     if streams is None:
         median_ms = float(np.median([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]))

@@ -91,6 +91,25 @@ class FlatThetaAgent(AbstractActorCritic):
         return _IncompatibleKeys(missing, unexpected)
 
     # -- device plumbing ----------------------------------------------------------------------------------------------
+    def _upload_packed(self, *arrays: np.ndarray) -> List[torch.Tensor]:
+        """ONE host -> device copy for several 4-byte-typed (float32 / int32) arrays: packed into one host buffer, sections
+        aligned to 256 bytes, returned as typed device views of the arrays' shapes (one H2D per batch; four
+        separate pageable copies cost four synchronous transfers)."""
+        offs, total = [], 0
+        for x in arrays:
+            assert x.dtype.itemsize == 4, x.dtype
+            offs.append(total)
+            total += (x.size + 63) // 64 * 64
+        host = np.empty(max(total, 64), dtype=np.int32)
+        for x, o in zip(arrays, offs):
+            host[o:o + x.size] = np.ascontiguousarray(x).reshape(-1).view(np.int32)
+        dev = torch.from_numpy(host).to(self.theta.device)
+        out = []
+        for x, o in zip(arrays, offs):
+            v = dev[o:o + x.size]
+            out.append((v.view(torch.float32) if x.dtype == np.float32 else v).view(x.shape))
+        return out
+
     def _guard(self):
         """Every C call runs with the agent's device current: the library keeps per-device state (CG tables in
         __constant__ memory, function attributes, side stream) keyed by hipGetDevice()."""

@@ -261,11 +261,7 @@ class CovariantAC(FlatThetaAgent):
         B = len(observations)
         acts = self._check_actions(actions, B)
         cfg = self._make_cfg(B, natoms)
-        dev = self.theta.device
-        d_pos = torch.from_numpy(pos).to(dev, non_blocking=True)
-        d_chg = torch.from_numpy(charges).to(dev, non_blocking=True)
-        d_bag = torch.from_numpy(bags).to(dev, non_blocking=True)
-        d_act = torch.from_numpy(acts).to(dev, non_blocking=True)
+        d_pos, d_chg, d_bag, d_act = self._upload_packed(pos, charges, bags, acts)
         out = _CovStep.apply(self.theta, self, cfg, d_pos, d_chg, d_bag, d_act)
         return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2],
                 'dists': self._dists(cfg, self._last_ws, d_bag)}
@@ -280,9 +276,8 @@ class CovariantAC(FlatThetaAgent):
         acts = self._check_actions(actions, B)
         dev = self.theta.device
         f64 = lambda x: None if x is None else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
-        return DeviceBatch(self._make_cfg(B, natoms), torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
-                           torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(logp), f64(adv),
-                           f64(ret))
+        d_pos, d_chg, d_bag, d_act = self._upload_packed(pos, charges, bags, acts)
+        return DeviceBatch(self._make_cfg(B, natoms), d_pos, d_chg, d_bag, d_act, f64(logp), f64(adv), f64(ret))
 
     def prepare_rollout(self, data: Dict[str, Any]) -> 'RolloutOnDevice':
         """Parse a whole rollout (the `data` dict of ppo.train) once; mini-batches are device gathers."""
@@ -291,9 +286,8 @@ class CovariantAC(FlatThetaAgent):
         acts = self._check_actions(data['act'], len(data['obs']))
         dev = self.theta.device
         f64 = lambda x: x.to(dev) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float64)).to(dev)
-        return RolloutOnDevice(self, natoms, torch.from_numpy(pos).to(dev), torch.from_numpy(charges).to(dev),
-                               torch.from_numpy(bags).to(dev), torch.from_numpy(acts).to(dev), f64(data['logp']),
-                               f64(data['adv']), f64(data['ret']))
+        d_pos, d_chg, d_bag, d_act = self._upload_packed(pos, charges, bags, acts)
+        return RolloutOnDevice(self, natoms, d_pos, d_chg, d_bag, d_act, f64(data['logp']), f64(data['adv']), f64(data['ret']))
 
     def _workspace(self, cfg: _lib.CovCfg, slot: int = 0) -> torch.Tensor:
         nbytes = C.c_size_t()
@@ -337,7 +331,7 @@ class CovariantAC(FlatThetaAgent):
         so the mini-batches of one epoch -- independent given theta -- can be in flight on several HIP streams."""
         lib = self._L()
         out = self.forward_batch(batch, slot)
-        ws = self._last_ws
+        ws = self._ws_cache[slot]  # (not self._last_ws: mini-batches of one epoch may be issued from several host threads)
         B = batch.cfg.B
         stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
         gout = torch.empty(3, B, dtype=torch.float32, device=self.theta.device)
@@ -361,7 +355,7 @@ class CovariantAC(FlatThetaAgent):
         B = len(observations)
         cfg = self._make_cfg(B, natoms)
         dev = self.theta.device
-        d_pos, d_chg, d_bag = (torch.from_numpy(x).to(dev) for x in (pos, charges, bags))
+        d_pos, d_chg, d_bag = self._upload_packed(pos, charges, bags)
         ws = self._workspace(cfg)
         out = torch.empty(3, B, dtype=torch.float32, device=dev)
         acts = torch.empty(B, 6, dtype=torch.float32, device=dev)
