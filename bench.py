@@ -8,7 +8,8 @@ One step = one pass of the hot path over one synthetic mini-batch (molgym/ppo.py
 the parsed mini-batch already resident in HBM.  N > 1: one process per GPU -- launched by torchrun, or by this
 script itself when it is started plainly with --gpus N -- with the flat gradient all-reduced over RCCL inside the
 timed region -- ONCE per `--allreduce-every` steps (default 10: the mini-batches of one ppo.train epoch accumulate
-locally and the epoch ends in one all-reduce, ppo.py:117-146 / molgym_amd/ppo.py::train; the line states the cadence);
+locally and the epoch ends in one all-reduce, ppo.py:117-146 / molgym_amd/ppo.py::train; the line states the cadence; the
+gradient buffer is zeroed on the same cadence at every N, `config.zero_grad_every_steps`);
 `--scaling weak` (default) gives every rank its own mini-batch of the configured size every step, `--scaling strong`
 deals the K WHOLE mini-batches round-robin to the ranks, the way `ppo.train` shards an epoch (total work fixed).
 Rank 0 prints ONE JSON line; `value` follows the contract
@@ -157,8 +158,12 @@ def main_internal(args):
     batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
     ac.theta.grad = torch.zeros_like(ac.theta)
 
+    every, count = max(1, args.allreduce_every), [0]
+
     def step():
-        ac.theta.grad.zero_()
+        if count[0] % every == 0:  # once per epoch of `every` mini-batches (see the covariant leg)
+            ac.theta.grad.zero_()
+        count[0] += 1
         return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
 
     for _ in range(args.warmup):
@@ -267,8 +272,11 @@ def main():
 
     def step(i=0, last=False):
         if streams is None:
-            if not use_dist or i % every == 0:
-                ac.theta.grad.zero_()  # (one GPU: every step, as before; N > 1: once per epoch -- the gradients accumulate)
+            if i % every == 0:
+                # once per epoch of `every` mini-batches, at any N: the reference zeroes the gradient per EPOCH and lets the
+                # epoch's mini-batches accumulate (ppo.py:117-131).  (Through round 2 the one-GPU run zeroed before every step
+                # -- one extra 4 us launch per step that the product does not make and that the N > 1 runs never had.)
+                ac.theta.grad.zero_()
             mine = args.scaling == 'weak' or i % world == rank
             if mine:
                 last_stats[0] = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
@@ -361,8 +369,9 @@ def main():
         torch.cuda.synchronize()
         k_parse = max(1, min(args.steps, 20 if B > 512 else args.steps))
         t2 = time.perf_counter()
-        for _ in range(k_parse):
-            ac.theta.grad.zero_()
+        for it in range(k_parse):
+            if it % every == 0:
+                ac.theta.grad.zero_()
             ac.ppo_minibatch(ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret']), 0.2, 0.5, 0.01)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t2) / k_parse
@@ -401,7 +410,8 @@ def main():
                        'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world),
                        # the same with the flops of the REAL atoms only (the kernels skip the padding the dense count includes)
                        'step_frac_ragged': f_ragged * value / 1e12 / (PEAK_F32_TFLOPS * world),
-                       'allreduce_every_steps': every if use_dist else None},
+                       'allreduce_every_steps': every if use_dist else None,
+                       'zero_grad_every_steps': every},
             'roofline': roof,
             'epoch_overlap': epoch_leg,
             'with_host_parse': parse_leg,
