@@ -179,7 +179,7 @@ def main_internal(args):
     line = {'metric': 'PPO mini-batch fwd+bwd samples/sec (internal, canvas_size=7)', 'value': B * args.steps / elapsed,
             'unit': 'samples/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'timed_region_ms': elapsed * 1e3,
             'config': {'workload': f'configs[0]: SchNet internal-coordinate actor-critic, zs={zs}, canvas_size={N}, '
                                    f'mini_batch={B}, 3B-molecule ragged batch resident in HBM'},
             'roofline': None, 'cpu_baseline': None}
@@ -264,11 +264,20 @@ def main():
     # weak: a step is `world` mini-batches, the all-reduced gradient their mean; strong: whole mini-batches, scale 1
     loss_scale = 1.0 / world if args.scaling == 'weak' else 1.0
     every = max(1, args.allreduce_every)
+    steps_asked = args.steps
+    if use_dist and args.scaling == 'strong':
+        # strong scaling deals WHOLE mini-batches round-robin: with K = 20 and 8 ranks a rank would time 2-3 mini-batches
+        # (about 1 ms).  K is rounded up to a multiple of world x allreduce_every: a whole number of epochs of `every` mini-batches
+        # in which every rank evaluates exactly K / world of them; the line reports both numbers
+        quantum = world * every
+        args.steps = -(-args.steps // quantum) * quantum
+        args.warmup = -(-max(args.warmup, 1) // world) * world
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
     last_stats = [torch.zeros(6, dtype=torch.float64, device=dev)]
+    n_allreduce = [0]
 
     def step(i=0, last=False):
         if streams is None:
@@ -282,6 +291,7 @@ def main():
                 last_stats[0] = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
             if use_dist and ((i + 1) % every == 0 or last):
                 dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL / xGMI per epoch
+                n_allreduce[0] += 1
             return last_stats[0]
         # epoch semantics of ppo.train: gradients of independent mini-batches accumulate; they are issued
         # round-robin on `inflight` streams with their own workspaces
@@ -300,6 +310,7 @@ def main():
     for i in range(args.warmup):
         step(i, i == args.warmup - 1)
     drain()
+    n_allreduce_warm = [n_allreduce[0]]
     # per-step HIP events on the launch stream (no synchronisation inside the timed region): median step time
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
@@ -325,6 +336,23 @@ def main():
         elapsed = t.item()
     if not torch.isfinite(stats).all():
         raise SystemExit('non-finite loss statistics')
+    dist_info = None
+    if use_dist:
+        # evidence for the scaling record: how many RCCL ranks there were, which device each drove, and that after the last
+        # all-reduce of the timed region every replica holds the SAME gradient (bit for bit: RCCL's ring sum is the same
+        # sequence of additions on every rank)
+        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev))
+        g = ac.theta.grad
+        probe = torch.stack([g.double().sum(), g.double().abs().sum(), g[::997].double().pow(2).sum()])
+        lo, hi = probe.clone(), probe.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+                     'rank_devices': [int(d.item()) for d in devs],
+                     'replicas_equal': bool(torch.equal(lo, hi)) and bool(torch.isfinite(probe).all()),
+                     'grad_abs_sum': float(probe[1].item()),
+                     'allreduces_in_timed_region': n_allreduce[0] - n_allreduce_warm[0]}
     # Second leg (one GPU, default run only): the same K mini-batch steps with three in flight on separate HIP streams, the
     # way ppo.train issues the mini-batches of ONE epoch -- the reference zeroes the gradient once per epoch and lets the
     # mini-batches accumulate into it (molgym/ppo.py:117-131), so they are independent given theta.  Reported beside the
@@ -396,6 +424,9 @@ def main():
             'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            # wall time between the two synchronisations that bracket the K timed steps (max over ranks): a thin sample is
+            # visible at a glance
+            'timed_region_ms': elapsed * 1e3,
             'config': {'workload': f'{args.config}: covariant actor-critic, zs={cfg["zs"]}, canvas_size='
                                    f'{cfg["canvas_size"]}, mini_batch={B} on this rank ({total_samples} over '
                                    f'{world} GPU(s), {args.scaling} scaling), beta={cfg["beta"]}, random-walk '
@@ -411,7 +442,13 @@ def main():
                        # the same with the flops of the REAL atoms only (the kernels skip the padding the dense count includes)
                        'step_frac_ragged': f_ragged * value / 1e12 / (PEAK_F32_TFLOPS * world),
                        'allreduce_every_steps': every if use_dist else None,
-                       'zero_grad_every_steps': every},
+                       'zero_grad_every_steps': every,
+                       'steps_requested': steps_asked,
+                       'steps_note': None if steps_asked == args.steps else
+                       f'--steps {steps_asked} rounded up to {args.steps} = a multiple of world x allreduce_every '
+                       f'({world} x {every}): strong scaling deals whole mini-batches round-robin, every rank times '
+                       f'{args.steps // world} of them'},
+            'dist': dist_info,
             'roofline': roof,
             'epoch_overlap': epoch_leg,
             'with_host_parse': parse_leg,

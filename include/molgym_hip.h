@@ -55,6 +55,10 @@ typedef struct mg_cov_cfg {
 } mg_cov_cfg;
 
 const char* mg_last_error(void);
+/* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
+ * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace.  */
+#define MG_ABI_VERSION 2
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.

@@ -69,15 +69,25 @@ _variants = {}
 DEFAULT_CHANNELS = (10, 4)  # num_channels_hidden, num_channels_per_element of the default build (arg_parser.py:55-60)
 
 
+ABI_VERSION = 2  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+
+
 def _bind(path):
     # torch first: its bundled HIP runtime must be the one this library binds to (loading the library before torch
     # leaves two runtimes in the process and the second one sees no device)
     import torch  # noqa: F401
     handle = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise RuntimeError(f'{path} does not export {name}: a stale build of the library (rebuild: '
+                               '`python -c "import __graft_entry__ as g; g.build()"`)') from None
         fn.restype = res
         fn.argtypes = args
+    got = handle.mg_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f'{path} speaks ABI version {got}, this binding {ABI_VERSION}: a stale prebuilt library (rebuild it)')
     return handle
 
 
@@ -86,23 +96,57 @@ def variant_path(channels):
     return LIB_PATH if tuple(channels) == DEFAULT_CHANNELS else os.path.join(_HERE, f'libmolgym_hip_c{ch}e{ce}.so')
 
 
+def _sources_mtime():
+    d = os.path.join(_HERE, 'csrc')
+    return max(os.path.getmtime(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(('.hip', '.inc', '.h')))
+
+
 def build_variant(channels, force=False):
     """hipcc build of the same sources for other channel counts (compile-time constants of the kernels): in-tree, next to
-    the default library.  Needs hipcc (present in the ROCm image on both the build container and the GPU box)."""
+    the default library.  Needs hipcc (present in the ROCm image on both the build container and the GPU box).
+    Several ranks of one torchrun launch may get here at once: the build is serialised by a file lock, goes to a temporary
+    file in the same directory and is moved into place atomically, so nobody ever dlopens a half-written library."""
+    import fcntl
     import subprocess
+    import tempfile
     path = variant_path(channels)
     src = os.path.join(_HERE, 'csrc', 'molgym_hip.hip')
-    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(
-            os.path.getmtime(os.path.join(_HERE, 'csrc', f)) for f in os.listdir(os.path.join(_HERE, 'csrc'))
-            if f.endswith(('.hip', '.inc', '.h'))):
+
+    def fresh():
+        return os.path.exists(path) and os.path.getmtime(path) >= _sources_mtime()
+
+    if not force and fresh():
         return path
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
         raise RuntimeError(f'num_channels_hidden={channels[0]}, num_channels_per_element={channels[1]} need their own build '
                            f'of the library and {hipcc} is not there')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', f'-DCH={channels[0]}',
-                           f'-DCE={channels[1]}', src, '-o', path])
+    try:
+        lock = open(path + '.lock', 'w')
+    except OSError as e:
+        raise RuntimeError(f'cannot build {path}: the package directory is not writable ({e}); build the variant once where '
+                           'it is (`python -c "from molgym_amd import _lib; _lib.build_variant((C, Ce))"`)') from None
+    with lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():  # another process built it while this one waited for the lock
+                return path
+            fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + '.', suffix='.tmp', dir=_HERE)
+            os.close(fd)
+            try:
+                subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+                                       f'-DCH={channels[0]}', f'-DCE={channels[1]}', src, '-o', tmp])
+                os.chmod(tmp, 0o755)
+                os.replace(tmp, path)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return path
+
+
+MAX_CHANNELS = (10, 5)  # csrc/common.h static_asserts: NLM * CH <= 256, 2 * NLM * CE <= 256
 
 
 def lib(channels=None):
@@ -113,9 +157,10 @@ def lib(channels=None):
     if channels is not None and tuple(channels) != DEFAULT_CHANNELS:
         key = tuple(int(c) for c in channels)
         if key not in _variants:
-            if key[0] < 1 or key[0] > 16 or key[1] < 1 or key[1] > 8:
+            if key[0] < 1 or key[0] > MAX_CHANNELS[0] or key[1] < 1 or key[1] > MAX_CHANNELS[1]:
                 raise RuntimeError(f'num_channels_hidden {key[0]} / num_channels_per_element {key[1]} outside what the '
-                                   'kernels were written for (1..16 / 1..8)')
+                                   f'kernels were written for (1..{MAX_CHANNELS[0]} / 1..{MAX_CHANNELS[1]}: one 256-thread '
+                                   'workgroup covers the 25 * C items of an atom)')
             handle = _bind(build_variant(key))
             ch, ce = C.c_int32(), C.c_int32()
             handle.mg_cov_channels(C.byref(ch), C.byref(ce))

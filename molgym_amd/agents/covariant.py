@@ -173,6 +173,7 @@ class CovariantAC(FlatThetaAgent):
         state['_last_ws'] = None
         state.pop('_last_cfg', None)
         state.pop('_ws_cache', None)
+        state.pop('_unchecked', None)
         return state
 
     # -- parameters -----------------------------------------------------------------------------
@@ -311,17 +312,23 @@ class CovariantAC(FlatThetaAgent):
                                                  _ptr(batch.charges), _ptr(batch.bags), _ptr(batch.actions),
                                                  _ptr(self.leb), _ptr(ws), ws.numel(), _ptr(out), self._s()))
         self._last_ws, self._last_cfg = ws, batch.cfg
+        # every (cfg, workspace) a training forward used since the last check: ppo.train keeps three mini-batches in flight on
+        # their own workspaces, and the list build raises its error flags in the workspace of the mini-batch it belongs to
+        self.__dict__.setdefault('_unchecked', {})[slot] = (batch.cfg, ws)
         return out
 
     def check_inputs(self) -> None:
-        """Surface the list-build flags of the LAST forward (mg_cov_check: canvases whose atoms are not compacted to the
-        front, TA / TE that do not match the charges) as RuntimeError.  It reads 16 bytes back, i.e. synchronises: ppo.train
-        calls it once per call, right after the first epoch's own device -> host copy."""
-        cfg, ws = getattr(self, '_last_cfg', None), self._last_ws
-        if cfg is None or ws is None:
-            return
+        """Surface the list-build flags of EVERY training forward since the last call (mg_cov_check: canvases whose atoms are
+        not compacted to the front, TA / TE that do not match the charges) as RuntimeError -- one (cfg, workspace) pair per
+        workspace slot, i.e. the most recent mini-batch of each stream ppo.train keeps in flight.  It reads 16 bytes back per
+        slot, i.e. synchronises: ppo.train calls it once per call, right after the first epoch's own device -> host copy.
+        A rank that evaluated nothing since the last call checks nothing (no stale cfg against a workspace the rollout's
+        sampling launches have since reused)."""
+        pending = self.__dict__.get('_unchecked') or {}
+        self._unchecked = {}
         with self._guard():
-            self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
+            for cfg, ws in pending.values():
+                self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
@@ -365,7 +372,8 @@ class CovariantAC(FlatThetaAgent):
             self._chk(self._L().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
                                                 _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(),
                                                 _ptr(acts), _ptr(out), self._s()))
-        self._last_ws = ws
+        self._last_ws, self._last_cfg = ws, None
+        self.__dict__.get('_unchecked', {}).pop(0, None)  # slot 0's workspace now holds this sampling launch's lists
         dists = self._dists(cfg, ws, d_bag)
         with self._guard():  # this path synchronises for the actions anyway: surface the list build's error flags
             self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
@@ -406,7 +414,8 @@ class CovariantAC(FlatThetaAgent):
                                                     _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), int(sample_ids[0]),
                                                     int(sample_ids[1]), mode, _ptr(ws), ws.numel(), _ptr(acts), _ptr(out),
                                                     self._s()))
-        self._last_ws = ws
+        self._last_ws, self._last_cfg = ws, None
+        self.__dict__.get('_unchecked', {}).pop(0, None)
         dists = self._dists(cfg, ws, canvas.bags.clone())
         newpos = canvas.append(acts, commit)
         host_a, host_p = acts.cpu().numpy(), newpos.cpu().numpy()  # the action rows and the positions they place

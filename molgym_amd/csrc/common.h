@@ -13,6 +13,11 @@
 #ifndef CE
 #define CE 4     // num_channels_per_element
 #endif
+// Several kernels cover the NLM * CH (atom, channel) items of an atom -- and the 2 * NLM * CE (row, output) pairs of the
+// mixer -- with ONE 256-thread workgroup and no loop (k_dot's channel-major transpose, k_dot_bwd, k_catbuild0(_bwd), the
+// fused heads): a build with more channels would silently leave the tail unwritten, so it does not compile.
+static_assert(NLM * CH <= 256, "num_channels_hidden <= 10: one 256-thread workgroup covers the NLM * CH items of an atom");
+static_assert(2 * NLM * CE <= 256, "num_channels_per_element <= 5: one 256-thread workgroup covers the 2 * NLM * CE mixer outputs");
 #define NLEV 3   // num_cg_levels
 #define NRADF 32 // radial features per level
 #define NLEB 1730

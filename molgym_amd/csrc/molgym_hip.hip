@@ -95,7 +95,7 @@ extern "C" int mg_profile_report(char* buf, size_t cap) {
   memcpy(buf, out.c_str(), out.size() + 1);
   return MG_OK;
 }
-extern "C" int mg_abi_version(void) { return 1; }
+extern "C" int mg_abi_version(void) { return MG_ABI_VERSION; }
 extern "C" int mg_cov_channels(int32_t* hidden, int32_t* per_element) {
   if (hidden) *hidden = CH;
   if (per_element) *per_element = CE;

@@ -497,18 +497,35 @@ def _shard_global_config(envs, num_steps_per_iter: int, rank: int, world: int):
     """`torchrun scripts/run.py` unchanged: every rank built ALL `num_envs` environments and was told the GLOBAL
     `num_steps_per_iter`.  Keep this rank's contiguous share of the environments and of the steps (so the job as a
     whole is the single-process configuration), and move the rollout RNG streams apart (numpy: environments /
-    stochastic bags; torch: action sampling) -- the model exists already, built from the same seed on every rank."""
-    size = envs.get_size()
-    if size % world or num_steps_per_iter % world or not hasattr(envs, 'environments'):
-        raise RuntimeError(f'data-parallel launch of an unchanged script: num_envs ({size}) and num_steps_per_iter '
-                           f'({num_steps_per_iter}) must be multiples of the world size ({world}), and the training '
-                           'container must expose `.environments`')
-    per = size // world
-    envs.environments = envs.environments[rank * per:(rank + 1) * per]
-    base = int(np.random.randint(2**31 - world))  # the same draw on every rank (same seed so far)
-    np.random.seed(base + rank)
-    torch.manual_seed(base + rank)
-    return envs, num_steps_per_iter // world
+    stochastic bags; torch: action sampling) -- the model exists already, built from the same seed on every rank.
+    Applies only when the `molgym` shim itself brought the process group up for a script that knows nothing about ranks
+    (DP_SHARD_GLOBAL_CONFIG; a rank-aware script initialises torch.distributed itself -- or sets MOLGYM_NO_DIST=1 -- and
+    passes per-rank environments / steps, which are then taken as they are).  The container is marked, so a second
+    batch_ppo call in the same process does not shard the already-sharded environments again."""
+    mark = getattr(envs, '_mg_dp_shard', None)
+    if mark is not None and mark[:2] == (rank, world):
+        # a second batch_ppo call on the same container (curriculum stage, resume): the environments ARE this rank's share
+        # already and the RNG streams were moved apart then -- only the (again global) step count is converted
+        size = mark[2]
+    else:
+        size = envs.get_size()
+        if not hasattr(envs, 'environments'):
+            raise RuntimeError('data-parallel launch of an unchanged script: the training container must expose `.environments`')
+        if size < world:
+            raise RuntimeError(f'data-parallel launch of an unchanged script: {size} environments cannot be dealt to {world} ranks')
+    if num_steps_per_iter % size:
+        raise RuntimeError(f'num_steps_per_iter ({num_steps_per_iter}) must be a multiple of num_envs ({size}) '
+                           '(ppo.py:175: every environment takes the same number of steps per iteration)')
+    if mark is None or mark[:2] != (rank, world):
+        # contiguous shares that differ by at most one environment: every environment belongs to exactly one rank, also when
+        # num_envs is not a multiple of the world size
+        lo, hi = (rank * size) // world, ((rank + 1) * size) // world
+        envs.environments = envs.environments[lo:hi]
+        envs._mg_dp_shard = (rank, world, size)
+        base = int(np.random.randint(2**31 - world))  # the same draw on every rank (same seed so far)
+        np.random.seed(base + rank)
+        torch.manual_seed(base + rank)
+    return envs, (num_steps_per_iter // size) * envs.get_size()
 
 
 def batch_ppo(
@@ -542,10 +559,12 @@ def batch_ppo(
     Under torch.distributed `envs` are THIS rank's environments and `num_steps_per_iter` counts this rank's steps;
     rank 0 alone evaluates, logs and saves."""
     dist, rank, world = _dist()
+    steps_per_iter_global = num_steps_per_iter * world  # per-rank environments / steps handed in by a rank-aware caller
     if dist is not None and DP_SHARD_GLOBAL_CONFIG:
+        steps_per_iter_global = num_steps_per_iter      # the script's own (global) configuration
         envs, num_steps_per_iter = _shard_global_config(envs, num_steps_per_iter, rank, world)
     total_num_steps = start_num_steps
-    num_iterations = (max_num_steps - total_num_steps) // (num_steps_per_iter * world)
+    num_iterations = (max_num_steps - total_num_steps) // steps_per_iter_global
     logging.info('Starting PPO')
     for iteration in range(num_iterations):
         logging.info(f'Iteration: {iteration}/{num_iterations - 1}, steps: {total_num_steps}')
@@ -582,7 +601,7 @@ def batch_ppo(
         if info_saver and rank == 0:
             opt_info['total_num_steps'] = total_num_steps
             info_saver.save(opt_info, name='opt')
-        total_num_steps += num_steps_per_iter * world
+        total_num_steps += steps_per_iter_global
 
         if rank == 0 and ((iteration % eval_freq == 0) or (iteration == num_iterations - 1)):
             eval_container = PPOBufferContainer(size=eval_envs.get_size(), gamma=gamma, lam=lam)

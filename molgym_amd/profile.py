@@ -112,6 +112,28 @@ def step_hbm(config, ms_per_step):
     return {'hbm_bytes_per_step': rec['hbm_bytes_per_step'], 'hbm_gbps': gbps, 'hbm_frac': gbps / PEAK_HBM_GBPS}
 
 
+def family_rooflines(per_step_ms, natoms, num_zs):
+    """`roofline.families`: per kernel family {flops per step (algorithmic, ragged), us per step (live HIP events around the
+    family's launches, summed), achieved TFLOP/s, fraction of the f32 peak}.  The families are the library's timing spans:
+    k_gemm_rows (every forward product and input adjoint of the encoder: row / column / shared-input GEMM launches),
+    k_gemm_dw (every weight gradient), k_heads_fwd / k_heads_bwd, k_dot (DotMatrix and its adjoint), and the two CG kernels."""
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from tools.flops import family_flops
+    fl = family_flops(natoms, num_zs)
+    fl['k_catbuild_mfma'] = catbuild_flops(natoms, False)[1] * 2      # executed (sparse-table) count, two levels
+    fl['k_catbuild_bwd_mfma'] = catbuild_flops(natoms, True)[1] * 2
+    out = {}
+    for name, ms in per_step_ms.items():
+        rec = {'us_per_step': ms * 1e3}
+        if name in fl and ms > 0:
+            tf = fl[name] / (ms * 1e-3) / 1e12
+            rec.update(flops_per_step=fl[name], achieved_tflops=tf, frac_f32_peak=tf / PEAK_F32_TFLOPS)
+        out[name] = rec
+    return out
+
+
 def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
     spans = kernel_spans(ac, batch)
     per_step = {k: v[0] * v[1] for k, v in spans.items()}
@@ -128,7 +150,8 @@ def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
                    'the f32 vector peak on gfx950), sparse CG projection on the vector ALUs; achieved / frac use the '
                    'DENSE-CG algorithmic count of SURVEY 8(d), achieved_executed / frac_executed the useful flops of '
                    'the sparse-table algorithm the kernel implements (MFMA tile padding not counted)',
-           'span_ms_per_step': per_step}
+           'span_ms_per_step': per_step,
+           'families': family_rooflines(per_step, natoms, len(cfg['zs']))}
     if dense is not None:
         out.update(achieved=dense / sec / 1e12, frac=dense / sec / 1e12 / PEAK_F32_TFLOPS,
                    achieved_dense=dense / sec / 1e12, achieved_executed=executed / sec / 1e12,

@@ -53,7 +53,11 @@ def main():
     util.set_seeds(seed=0)  # like run.py: the same seed on every rank
     ac = RolloutAC()
     before = {k: v.clone() for k, v in ac.state_dict().items()}
-    envs = SimpleEnvContainer([FakeMolEnv(5, ZS, (0, 1 + i % 2, 2)) for i in range(4)])
+    num_envs, steps = int(os.environ.get('MG_TEST_NUM_ENVS', '4')), int(os.environ.get('MG_TEST_STEPS', '16'))
+    all_envs = [FakeMolEnv(5, ZS, (0, 1 + i % 2, 2)) for i in range(num_envs)]
+    for i, e in enumerate(all_envs):
+        e.env_id = i
+    envs = SimpleEnvContainer(all_envs)
     eval_envs = SimpleEnvContainer([FakeMolEnv(5, ZS, (0, 2, 1))])
     saver = Saver()
     stored = []
@@ -68,13 +72,13 @@ def main():
 
     hot.batch_rollout = counting_rollout
     batch_ppo(envs=envs, eval_envs=eval_envs, ac=ac, optimizer=torch.optim.Adam(ac.parameters(), lr=1e-2), gamma=1.0,
-              max_num_steps=32, num_steps_per_iter=16, mini_batch_size=4, clip_ratio=0.2, vf_coef=0.5, entropy_coef=0.01,
+              max_num_steps=2 * steps, num_steps_per_iter=steps, mini_batch_size=4, clip_ratio=0.2, vf_coef=0.5, entropy_coef=0.01,
               max_num_train_iters=2, lam=0.97, target_kl=1e9, gradient_clip=0.5, eval_freq=1, num_eval_episodes=1,
               info_saver=saver)
     import torch.distributed as dist
     rank = dist.get_rank()
     torch.save({'world': dist.get_world_size(), 'initialised_by_shim': hot.DP_SHARD_GLOBAL_CONFIG,
-                'local_envs': envs.get_size(), 'sd': ac.state_dict(),
+                'local_envs': envs.get_size(), 'env_ids': [e.env_id for e in envs.environments], 'sd': ac.state_dict(),
                 'moved': any(not torch.equal(before[k], v) for k, v in ac.state_dict().items()),
                 'rollout_seed_probe': float(np.random.rand()) + float(torch.rand(1)),
                 'train_log': saver.records.get('train', []), 'steps_stored_per_iteration': stored[0]},

@@ -15,6 +15,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -224,3 +225,57 @@ def test_shim_initialises_the_process_group_for_an_unchanged_script(tmp_path):
     # rank 0 logged 16 steps per iteration = the GLOBAL num_steps_per_iter, episode statistics over both ranks
     assert r0['train_log'] and all(rec['total_num_steps'] % 16 == 0 for rec in r0['train_log'])
     assert r0['steps_stored_per_iteration'] == r1['steps_stored_per_iteration'] == 8
+
+
+def test_shim_deals_an_odd_number_of_environments_to_four_ranks(tmp_path):
+    """`torchrun --nproc-per-node 4 script.py` with num_envs = 5 (not a multiple of the world size): every environment is
+    stepped by exactly one rank (shares 1, 1, 1, 2), every environment takes the same number of steps per iteration, the
+    job as a whole stores the script's GLOBAL num_steps_per_iter, and the replicas stay identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'shim4')
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), MOLGYM_DIST_BACKEND='gloo',
+               OMP_NUM_THREADS='1', MG_TEST_NUM_ENVS='5', MG_TEST_STEPS='20')
+    env.pop('MOLGYM_REFERENCE', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'tests', 'shim_dp_script.py'), out]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    recs = [torch.load(f'{out}.rank{r}.pt', weights_only=False) for r in range(4)]
+    assert all(r['world'] == 4 and r['initialised_by_shim'] for r in recs)
+    ids = sorted(i for r in recs for i in r['env_ids'])
+    assert ids == [0, 1, 2, 3, 4]                                            # every environment exactly once
+    assert sorted(r['local_envs'] for r in recs) == [1, 1, 1, 2]
+    # 20 global steps per iteration = 4 per environment: a rank stores 4 x (its environments)
+    assert [r['steps_stored_per_iteration'] for r in recs] == [4 * r['local_envs'] for r in recs]
+    assert sum(r['steps_stored_per_iteration'] for r in recs) == 20
+    assert all(torch.equal(recs[0]['sd'][k], r['sd'][k]) for r in recs[1:] for k in recs[0]['sd'])
+    assert recs[0]['moved']
+    assert recs[0]['train_log'] and all(rec['total_num_steps'] % 20 == 0 for rec in recs[0]['train_log'])
+
+
+def test_global_config_sharding_is_idempotent_per_container():
+    """a second batch_ppo call on the same container (curriculum, resume) must not shard the already-sharded environments
+    again nor reseed the RNG streams; only the (again global) step count is converted"""
+    from molgym_amd import ppo
+
+    class Box:
+        def __init__(self, n):
+            self.environments = list(range(n))
+
+        def get_size(self):
+            return len(self.environments)
+
+    np.random.seed(3)
+    box = Box(5)
+    envs, steps = ppo._shard_global_config(box, 20, rank=3, world=4)
+    assert envs.environments == [3, 4] and steps == 8
+    probe = np.random.get_state()[1][:4].copy()
+    envs, steps = ppo._shard_global_config(box, 40, rank=3, world=4)
+    assert envs.environments == [3, 4] and steps == 16
+    assert np.array_equal(np.random.get_state()[1][:4], probe)  # no second reseed
+    with pytest.raises(RuntimeError):
+        ppo._shard_global_config(Box(3), 12, rank=0, world=4)   # fewer environments than ranks
+    with pytest.raises(RuntimeError):
+        ppo._shard_global_config(Box(5), 12, rank=0, world=4)   # steps not a multiple of num_envs

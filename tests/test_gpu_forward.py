@@ -25,6 +25,29 @@ def test_outputs_match_oracle(built_lib):
         assert rel_err(out[k], exp[k]) < 1e-5, k
 
 
+def test_evaluate_actions_matches_oracle(built_lib):
+    """`agent.evaluate_actions(obs, actions)` -- the name BASELINE.json's north_star uses for action evaluation
+    (/root/reference/molgym/agents/base.py:17-19 spells it step(observations, actions); ppo.py:26 is its caller) -- against the
+    oracle: outputs to 1e-5 and, through its autograd node, every parameter gradient."""
+    from tests.helpers import assert_grads, grad_report
+    ac, ref, cfg = make_pair('cfg2', seed=21)
+    data = make_batch(17, cfg['canvas_size'], cfg['zs'], seed=9)
+    out = ac.evaluate_actions(data['obs'], data['act'])
+    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+    assert torch.equal(out['a'].cpu(), torch.as_tensor(data['act'], dtype=torch.float32))
+    assert len(out['dists']) == 4  # focus, element, distance, orientation (covariant/agent.py:318-334)
+    (0.3 * out['logp'].sum() + out['v'].sum() - 0.02 * out['ent'].sum()).backward()
+    (0.3 * exp['logp'].sum() + exp['v'].sum() - 0.02 * exp['ent'].sum()).backward()
+    assert_grads(grad_report(ac.theta.grad, dict(ref.named_parameters()), ac.slot_table))
+    # and it IS the training-path entry: same numbers as step(obs, actions)
+    with torch.no_grad():
+        again = ac.step(data['obs'], data['act'])
+    for k in ('logp', 'ent', 'v'):
+        assert torch.equal(out[k].detach(), again[k]), k
+
+
 def test_outputs_match_oracle_so3_without_beta(built_lib):
     ac, ref, cfg, data, out, exp = _run(beta=None, seed=2)
     for k in ('logp', 'ent', 'v'):

@@ -68,6 +68,17 @@ def test_outputs_and_gradients_match_oracle(built_lib):
     assert not bad, bad
 
 
+def test_evaluate_actions_matches_oracle(built_lib):
+    """the north_star's spelling of action evaluation (agents/base.py:17-19) on the internal-coordinate agent"""
+    ac, ref = _pair(5)
+    data = make_batch_internal(13, N, ZS, seed=2)
+    with torch.no_grad():
+        out = ac.evaluate_actions(data['obs'], data['act'])
+        exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k], exp[k]) < 1e-5, k
+
+
 def test_small_canvases_and_masks(built_lib):
     """n = 0, 1, 2 exercise the action masks (distance / angle / dihedral / kappa) and the null-atom focus."""
     ac, ref = _pair(3, width=64)

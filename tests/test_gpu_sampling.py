@@ -151,6 +151,30 @@ def test_list_build_errors_are_reported(built_lib):
     assert b'compacted' in built_lib.mg_last_error() or b'TA' in built_lib.mg_last_error()
 
 
+def test_check_inputs_covers_every_workspace_slot(built_lib):
+    """ppo.train keeps three mini-batches in flight on their own workspaces; check_inputs() must read the error flags of
+    EVERY slot used since the last call, not only the last mini-batch's -- and forget them afterwards"""
+    ac, ref, cfg = make_pair('cfg2', seed=37)
+    d = make_batch(6, cfg['canvas_size'], cfg['zs'], seed=19)
+    good = ac.prepare_batch(d['obs'], d['act'])
+    bad = ac.prepare_batch(d['obs'], d['act'])
+    charges = bad.charges.clone()
+    charges[int((charges > 0).sum(dim=1).argmax()), 0] = 0  # hole at the front of a populated canvas
+    bad.charges = charges
+    ac.forward_batch(good, slot=0)
+    ac.forward_batch(bad, slot=1)   # the inconsistent one is NOT the last mini-batch issued
+    ac.forward_batch(good, slot=2)
+    with pytest.raises(RuntimeError):
+        ac.check_inputs()
+    ac.check_inputs()               # nothing evaluated since: nothing to check, nothing stale to trip over
+    ac.forward_batch(good, slot=1)
+    ac.check_inputs()
+    # a sampling launch reuses slot 0's workspace: the cfg of the earlier training forward must not be checked against it
+    ac.forward_batch(good, slot=0)
+    ac.step(d['obs'][:3])
+    ac.check_inputs()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
 def test_agents_on_two_devices_in_one_process(built_lib):
     """per-device library state (CG tables, function attributes, side stream): an agent on cuda:1 while cuda:0 is the

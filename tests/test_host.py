@@ -69,7 +69,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(built_lib, name)
-    assert built_lib.mg_abi_version() == 1
+    # one version number in three places: the header's define, what the library returns, what the binding accepts
+    header_version = int(re.search(r'#define\s+MG_ABI_VERSION\s+(\d+)', header).group(1))
+    assert built_lib.mg_abi_version() == header_version == _lib.ABI_VERSION
+
+
+def test_channel_counts_outside_the_kernels_range_are_refused():
+    """the kernels cover the 25 * C items of an atom with one 256-thread workgroup (static_asserts in csrc/common.h): the
+    binding refuses the builds that could not compile instead of starting hipcc"""
+    from molgym_amd import _lib
+    for bad in ((11, 4), (16, 4), (10, 6), (0, 4)):
+        with pytest.raises(RuntimeError):
+            _lib.lib(bad)
 
 
 def test_invalid_configuration_is_reported(built_lib):

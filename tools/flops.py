@@ -73,6 +73,42 @@ def step_flops(natoms_list, num_zs):
     return 3 * sum(forward_flops(int(n), num_zs) for n in natoms_list)
 
 
+def family_flops(natoms_list, num_zs):
+    """Algorithmic flops of ONE fwd+bwd step (ragged: real atoms only) per kernel FAMILY -- the names are the library's
+    live-timing spans (mg_profile_report).  Every dense product is counted once forward, once for the adjoint w.r.t. its
+    input (`k_gemm_rows`: the row / column / shared-input GEMM launches) and once for its weight gradient (`k_gemm_dw`);
+    the heads' dense layers run inside `k_heads_fwd` / `k_heads_bwd` (their weight gradients in `k_gemm_dw`)."""
+    co = num_zs * CE
+    M = [2 * l + 1 for l in range(L + 1)]
+    nlat, nlat_e = (L + 2) * co * 2, (L + 2) * CE * 2
+    out = dict(k_gemm_rows=0.0, k_gemm_dw=0.0, k_heads_fwd=0.0, k_heads_bwd=0.0, k_dot=0.0)
+    for n in natoms_list:
+        n = int(n)
+        radial = n * n * 3 * (L + 1) * 2 * 32 * 2 * C
+        edge_mix = dot = atom_mix = 0
+        for k in range(3):
+            parts = [C] if k == 0 else [C] * 5
+            dot += n * n * sum(tt * M[l] * 8 for l, tt in enumerate(parts))
+            c_in = (0 if k == 0 else C) + sum(parts) + C
+            edge_mix += n * n * (L + 1) * c_in * C * 8
+            tau_cat = [3 * C, C, C, C, C] if k == 0 else [C * (2 * b + 1) for b in NBLK]
+            atom_mix += n * sum(tau_cat[l] * (co if k == 2 else C) * M[l] * 8 for l in range(L + 1))
+        enc = radial + edge_mix + atom_mix
+        per_atom_mlp = n * (2 * nlat * W + 2 * W) + n * (2 * nlat * W + 2 * W * W)
+        per_sample_mlp = (2 * nlat * W + 2 * W * num_zs) + (2 * nlat_e * W + 2 * W * 2 * G) + (2 * W * W + 2 * W)
+        mixer_mix = sum(CE * (b + 2) * CE * M[l] * 8 for l, b in enumerate(NBLK))
+        mixer_cg = CE * 25 * 2 + sum(CE * M[a] * M[b] * 6 + CE * M[a] * M[b] * sum(M[l] for l in range(abs(a - b), min(a + b, L) + 1)) * 4
+                                     for a in range(L + 1) for b in range(L + 1))
+        head_dense = per_atom_mlp + per_sample_mlp + mixer_mix
+        head_other = n * co * 25 * 6 + mixer_cg + 1730 * (25 * CE * 8 + 200)
+        out['k_gemm_rows'] += 2 * enc                      # forward + input adjoint
+        out['k_gemm_dw'] += enc + head_dense               # every weight gradient
+        out['k_heads_fwd'] += head_dense + head_other
+        out['k_heads_bwd'] += head_dense + 2 * head_other  # input adjoints (the non-linear parts cost ~2x backward)
+        out['k_dot'] += 3 * dot                            # forward + two input adjoints
+    return out
+
+
 if __name__ == '__main__':
     for n, z in ((7, 3), (12, 5), (20, 5), (40, 5)):
         tot, terms = forward_flops(n, z, terms=True)
