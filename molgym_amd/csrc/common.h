@@ -28,7 +28,7 @@ static_assert(2 * NLM * CE <= 256, "num_channels_per_element <= 5: one 256-threa
 #define MG_EXP 0
 #endif
 #ifdef MG_TS
-__device__ unsigned long long g_ts[64];
+__device__ unsigned long long g_ts[128];
 __device__ int g_ts_block;
 #define TS(i) do { if (blockIdx.x == g_ts_block && blockIdx.y == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
 #define TSY(i) do { if (blockIdx.x == g_ts_block && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
@@ -36,6 +36,12 @@ __device__ int g_ts_block;
 #define TS(i) do { } while (0)
 #define TSY(i) do { } while (0)
 #endif
+
+// Workgroup barrier that waits for the wave's LDS traffic ONLY.  __syncthreads() is "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier":
+// in a kernel whose phases each end in fire-and-forget global stores / atomics it adds a full store round trip (1-2 us on a
+// latency-bound launch) to every phase.  Use where the phases hand data over through LDS and nothing a wave wrote to global
+// memory is read back by the workgroup (loads still in flight are waited for by the compiler at their first use).
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct cf {  // complex float
   float r, i;

@@ -2,6 +2,7 @@
 // One translation unit: kernels live in the .inc files next to this one.
 #include <mutex>
 #include "state.inc"
+#include "level0.inc"
 #include "sampling.inc"
 #include "heads_fused.inc"
 #include "backward.inc"
@@ -253,7 +254,39 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
                   w.lin_in.b_off >= 0 ? theta + w.lin_in.b_off : nullptr, 2 * CH, w.scal, w.A0};
   const unsigned n_in = (unsigned)((TA * 2 * CH + 255) / 256);
   bool input_done = false;
-  if (TE > 0) {
+  // small mini-batches: inputs -> A[1] (geometry, input Linear, the 15 radial Linears and the whole of level 0) in ONE launch
+  const bool fused0 = level0_fused(lists_done, c, w);
+  if (fused0) {
+    L0Args la;
+    memset(&la, 0, sizeof(la));
+    la.pos = pos; la.charges = charges; la.bags = bags; la.theta = theta;
+    la.N = N; la.Z = Z; la.zs = zs; la.charge_scale = (float)maxz; la.bag_scale = c->bag_scale;
+    la.rad0 = (int)P.rad_scales[0]; la.lvl_stride = (int)(P.rad_scales[1] - P.rad_scales[0]);
+    la.soft_rad = soft_rad; la.soft_width = soft_width;
+    la.in_mf = w.lin_in.mf; la.in_ldf = w.lin_in.ldf; la.in_bias = w.lin_in.b_off >= 0 ? theta + w.lin_in.b_off : nullptr;
+    la.rad_mb0 = w.rad[0][0].mb; la.rad_stride = (int)(w.rad[0][1].mb - w.rad[0][0].mb);
+    for (int kl = 0; kl < 15; ++kl)
+      if (w.rad[kl / 5][kl % 5].mb != la.rad_mb0 + (size_t)kl * la.rad_stride || w.rad[kl / 5][kl % 5].ldb != NRADF)
+        MG_FAIL(MG_EINVAL, "level-0 kernel: radial weights are not at a fixed stride");
+    la.scal = w.scal; la.A0 = w.A0; la.r = w.r; la.em = w.em; la.Y = w.Y;
+    for (int k = 0; k < 3; ++k) la.phi[k] = w.phi[k];
+    la.ld_E0 = w.ld_e[1][0]; la.ld_rad1 = w.ld_e[1][0]; la.ld_rad2 = w.ld_e[2][0];
+    for (int l = 0; l < 5; ++l) {
+      la.edge_mb[l] = w.edge[0][l].mb; la.edge_ldb[l] = w.edge[0][l].ldb;
+      la.atom_mb[l] = w.atom[0][l].mb; la.atom_ldb[l] = w.atom[0][l].ldb;
+      la.cat_e0[l] = w.cat_e[0][l]; la.ld_e0[l] = w.ld_e[0][l]; la.rcol0[l] = w.rcol[0][l];
+      la.E0[l] = w.cat_e[1][l];
+      la.rad1[l] = w.cat_e[1][l] + w.rcol[1][l]; la.rad2[l] = w.cat_e[2][l] + w.rcol[2][l];
+      la.cat_a0[l] = w.cat_a[0][l]; la.ld_a0[l] = w.ld_a[0][l];
+      la.A1[l] = w.A[1][l];
+      if (w.ld_e[1][l] != la.ld_E0 || w.ld_e[2][l] != la.ld_rad2)
+        MG_FAIL(MG_EINVAL, "level-0 kernel: unexpected row strides");
+    }
+    ProfScope prof(s, "k_level0");
+    hipLaunchKernelGGL(k_level0_fwd, dim3(TA), dim3(L0_T), 0, s, la, w.L);
+    LAUNCH_CHECK();
+    input_done = true;
+  } else if (TE > 0) {
     GeomArgs ga = {TE, N, pos, theta, (int)P.rad_scales[0], (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]),
                    soft_rad, soft_width, {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}}};
     const unsigned n_geom = (unsigned)((4 * TE + 255) / 256);
@@ -265,7 +298,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     }
     LAUNCH_CHECK();
   }
-  if (TE > 0 && TA > 0) {
+  if (TE > 0 && TA > 0 && !fused0) {
     // the radial Linears of all three levels depend on the geometry only: side stream, beside the input Linear
     // and the first DotMatrix (they fill the radial columns of cat_e[k]; joined before the first edge cat-mix)
     hipStream_t ss = side_fork(s);
@@ -300,7 +333,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     hipLaunchKernelGGL(k_input_linear, dim3(n_in), dim3(256), 0, s, ia, w.L);
     LAUNCH_CHECK();
   }
-  for (int k = 0; k < 3 && TA > 0; ++k) {
+  for (int k = fused0 ? 1 : 0; k < 3 && TA > 0; ++k) {
     // --- edge level k (cormorant EdgeLevel: DotMatrix, cat-mix, soft mask) ---
     if (k == 0) {
       hipLaunchKernelGGL(k_dot0, dim3((TE * CH + 255) / 256), dim3(256), 0, s, TE, w.L, w.A0, w.cat_e[0][0],
@@ -578,7 +611,7 @@ extern "C" int mg_so3_density(int32_t B, int64_t S, int32_t Bp, const float* coe
 // debug builds only (tools/ts_heads.sh): read the phase timestamps (100 MHz ticks) and choose the stamped workgroup
 extern "C" int mg_debug_ts(unsigned long long* out, int block) {
   HIP_CHECK(hipDeviceSynchronize());
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 64));
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 128));
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_block), &block, sizeof(int)));
   return MG_OK;
 }

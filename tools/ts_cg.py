@@ -23,7 +23,7 @@ data = make_batch(cfg['batch'], cfg['canvas_size'], cfg['zs'], seed=0)
 batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
 lib = _lib.lib()
 lib.mg_debug_ts.argtypes = [C.c_void_p, C.c_int]
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 for blk in (0, 8, 801):
     lib.mg_debug_ts(buf, blk)
     for _ in range(3):

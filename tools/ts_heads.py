@@ -26,7 +26,7 @@ def main():
     natoms = [sum(1 for it in o[0] if cfg['zs'][it[0]] != 0) for o in data['obs']]
     lib = _lib.lib()
     lib.mg_debug_ts.argtypes = [C.c_void_p, C.c_int]
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 128)()
     for target in (max(natoms), int(np.median(natoms)), -max(natoms)):
         blk = natoms.index(abs(target))
         if target < 0:  # stamp the first ATOM of that sample (k_catbuild_bwd is one workgroup per atom)
