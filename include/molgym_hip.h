@@ -57,8 +57,8 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace.  */
-#define MG_ABI_VERSION 2
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step.  */
+#define MG_ABI_VERSION 3
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
@@ -194,6 +194,25 @@ int mg_int_backward(const mg_int_cfg* cfg, const float* theta, const int32_t* mo
 int mg_ppo_loss(int32_t B, const float* pred, const double* old_logp, const double* adv, const double* ret,
                 double clip_ratio, double vf_coef, double entropy_coef, double* stats, float* gout,
                 void* stream);
+
+/* ---- one PPO mini-batch in one call: step(obs, actions) -> loss -> backward (molgym/ppo.py:124-131) ---------------------
+ * What the device-resident update loop of ppo.train does per mini-batch: mg_cov_forward, mg_ppo_loss, mg_cov_backward on the
+ * same stream, with
+ *   out [3][B], gout [3][B] f32 and stats[6] f64 caller-owned (kept: `out` is what step() returned, gout = d loss / d out);
+ *   loss_scale multiplies gout (this rank's share of a data-parallel mini-batch; 1 otherwise);
+ *   stats_accum[6] f64 (may be NULL): += loss_scale * stats, atomically -- the epoch's mean of mini-batch means;
+ *   gradients ACCUMULATE into grad_theta.
+ * graph_slot < 0: ~27 stream launches.  graph_slot in [0, 8): the launches are recorded, the kernel nodes of this host
+ * thread's cached graph number graph_slot are updated in place (grids and arguments follow the mini-batch's ragged sizes) and
+ * ONE hipGraphLaunch is issued -- ~30 us of host time instead of ~250 (the update loop is host-bound otherwise).  Mini-batches
+ * in flight on different streams must use different slots.  Falls back to the stream launches by itself where a graph cannot
+ * express the step (side streams of the large configurations); *used_graph_host (may be NULL) reports which form ran.
+ * MG_GRAPH=0 in the environment disables the graph form.                                                              */
+int mg_cov_ppo_step(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges, const float* bags,
+                    const float* actions, const float* lebedev, void* workspace, size_t workspace_bytes,
+                    const double* old_logp, const double* adv, const double* ret, double clip_ratio, double vf_coef,
+                    double entropy_coef, double loss_scale, float* out, float* gout, double* stats, double* stats_accum,
+                    float* grad_theta, int32_t graph_slot, int32_t* used_graph_host, void* stream);
 
 /* ---- GAE-lambda over concatenated trajectories (buffer.py:74-82) ------------------ */
 /* path_off [P+1] i32 start offsets; rew, val [T] f64; last_val [P] f64.

@@ -158,6 +158,8 @@ class CovariantAC(FlatThetaAgent):
         self.theta = torch.nn.Parameter(self._init_theta(total))
         self.register_buffer('leb', torch.from_numpy(lebedev_table()), persistent=False)
         self._last_ws = None
+        # ppo_minibatch issues its launches as one updated hipGraph launch (include/molgym_hip.h: mg_cov_ppo_step)
+        self.use_graphs = True
         self.to(self.device)
 
     def _chk(self, rc):
@@ -174,6 +176,7 @@ class CovariantAC(FlatThetaAgent):
         state.pop('_last_cfg', None)
         state.pop('_ws_cache', None)
         state.pop('_unchecked', None)
+        state.pop('_last_out', None)
         return state
 
     # -- parameters -----------------------------------------------------------------------------
@@ -331,27 +334,37 @@ class CovariantAC(FlatThetaAgent):
                 self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
-                      loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
-        """One compute_loss forward + backward (molgym/ppo.py:124-131) entirely on the device:
+                      loss_scale: float = 1.0, slot: int = 0, stats_accum: Optional[torch.Tensor] = None,
+                      graph: Optional[bool] = None) -> torch.Tensor:
+        """One compute_loss forward + backward (molgym/ppo.py:124-131) entirely on the device, ONE C call (mg_cov_ppo_step):
         step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED (atomically) into theta.grad.
-        Returns the 6 float64 loss statistics (device tensor, no sync).  `slot` selects an independent workspace,
-        so the mini-batches of one epoch -- independent given theta -- can be in flight on several HIP streams."""
+        Returns the 6 float64 loss statistics (device tensor, no sync); `stats_accum` (6 float64, optional) additionally gets
+        loss_scale x statistics added on the device (ppo.train's epoch mean without a tensor per mini-batch).  `slot` selects an
+        independent workspace AND an independent cached graph, so the mini-batches of one epoch -- independent given theta --
+        can be in flight on several HIP streams.  `graph` (default: on, MG_GRAPH=0 in the environment turns it off): the ~27
+        launches of the step are recorded and issued as one hipGraph launch whose kernel nodes are updated in place
+        (include/molgym_hip.h: the update loop is otherwise bound by the host's launch rate); the library falls back to plain
+        stream launches where a graph cannot express the step."""
         lib = self._L()
-        out = self.forward_batch(batch, slot)
-        ws = self._ws_cache[slot]  # (not self._last_ws: mini-batches of one epoch may be issued from several host threads)
+        ws = self._workspace(batch.cfg, slot)
         B = batch.cfg.B
-        stats = torch.empty(6, dtype=torch.float64, device=self.theta.device)
-        gout = torch.empty(3, B, dtype=torch.float32, device=self.theta.device)
+        dev = self.theta.device
+        out = torch.empty(3, B, dtype=torch.float32, device=dev)
+        gout = torch.empty(3, B, dtype=torch.float32, device=dev)
+        stats = torch.empty(6, dtype=torch.float64, device=dev)
+        if self.theta.grad is None:
+            self.theta.grad = torch.zeros_like(self.theta)
+        use_graph = self.use_graphs if graph is None else graph
+        used = C.c_int32(0)
         with self._guard():
-            self._chk(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
-                                       vf_coef, entropy_coef, _ptr(stats), _ptr(gout), self._s()))
-            if loss_scale != 1.0:
-                gout.mul_(loss_scale)
-            if self.theta.grad is None:
-                self.theta.grad = torch.zeros_like(self.theta)
-            self._chk(lib.mg_cov_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
-                                           _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws),
-                                           ws.numel(), _ptr(gout), _ptr(self.theta.grad), self._s()))
+            self._chk(lib.mg_cov_ppo_step(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+                                          _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
+                                          _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef, entropy_coef,
+                                          float(loss_scale), _ptr(out), _ptr(gout), _ptr(stats), _ptr(stats_accum),
+                                          _ptr(self.theta.grad), slot if use_graph else -1, C.byref(used), self._s()))
+        self._last_ws, self._last_cfg, self._last_out = ws, batch.cfg, out
+        self.last_step_used_graph = bool(used.value)
+        self.__dict__.setdefault('_unchecked', {})[slot] = (batch.cfg, ws)
         return stats
 
     def _step_sample(self, observations: List[ObservationType]) -> Dict[str, Any]:

@@ -607,6 +607,55 @@ extern "C" int mg_so3_density(int32_t B, int64_t S, int32_t Bp, const float* coe
   return MG_OK;
 }
 
+// ---- one PPO mini-batch: forward -> float64 loss -> backward in ONE call (and, when asked, ONE graph launch) -----------------
+// molgym/ppo.py:124-131 (compute_loss + loss.backward()) for the device-resident path of ppo.train.
+// graph_slot < 0: the ~27 launches go to `stream` one by one (what mg_cov_forward + mg_ppo_loss + mg_cov_backward do).
+// graph_slot >= 0: the same launch code RECORDS instead (launch.inc); the recording updates the kernel nodes of this host
+// thread's cached hipGraphExec number `graph_slot` in place (grids and arguments change with every mini-batch's ragged sizes)
+// and one hipGraphLaunch replaces the launches.  Mini-batches in flight on different streams use different slots.  Anything
+// the graph form cannot express (side streams of the large configurations, asynchronous memsets) makes the call fall back to
+// the eager form by itself; *used_graph reports which one ran.
+extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges, const float* bags,
+                               const float* actions, const float* leb, void* ws, size_t ws_bytes, const double* old_logp,
+                               const double* adv, const double* ret, double clip_ratio, double vf_coef, double entropy_coef,
+                               double loss_scale, float* out, float* gout, double* stats, double* stats_accum,
+                               float* grad_theta, int32_t graph_slot, int32_t* used_graph, void* stream) {
+  if (!c || !out || !gout || !stats || !grad_theta) MG_FAIL(MG_EINVAL, "mg_cov_ppo_step: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  auto run = [&]() -> int {
+    int rc = cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
+                       entropy_coef, stats, gout, loss_scale, stats_accum);
+    LAUNCH_CHECK();
+    return mg_cov_backward(c, theta, pos, charges, bags, actions, leb, ws, ws_bytes, gout, grad_theta, stream);
+  };
+  if (used_graph) *used_graph = 0;
+  static int graphs_on = -1;
+  if (graphs_on < 0) { const char* e = getenv("MG_GRAPH"); graphs_on = e ? atoi(e) : 1; }
+  const bool want_graph = graph_slot >= 0 && graph_slot < MG_GRAPH_SLOTS && graphs_on && !g_prof_on &&
+                          c->TE < MG_SIDE_MIN_EDGES;  // one stream only: the side-stream forks of the large configurations are events
+  if (want_graph) {
+    int rc = ensure_tables();  // (its one-time uploads synchronise: not inside a recording)
+    if (rc) return rc;
+    g_rec.begin(s);
+    rc = run();
+    g_rec.end();
+    if (rc) return rc;
+    if (!g_rec.unsupported && !g_rec.recs.empty()) {
+      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][graph_slot], s);
+      if (e == hipSuccess) {
+        if (used_graph) *used_graph = 1;
+        return MG_OK;
+      }
+      (void)hipGetLastError();
+      static bool warned = false;
+      if (!warned) { fprintf(stderr, "molgym_hip: graph launch failed (%s); running eagerly\n", hipGetErrorString(e)); warned = true; }
+    }
+  }
+  return run();
+}
+
 #ifdef MG_TS
 // debug builds only (tools/ts_heads.sh): read the phase timestamps (100 MHz ticks) and choose the stamped workgroup
 extern "C" int mg_debug_ts(unsigned long long* out, int block) {

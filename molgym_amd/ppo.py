@@ -129,6 +129,11 @@ class _DeviceRunner:
         self.streams = []
         if self.dev.type == 'cuda' and len(data['obs']) > mini_batch_size:
             self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+        # agents whose ppo_minibatch adds (share x statistics) into an epoch accumulator on the device (CovariantAC: inside the
+        # loss kernel): no tensor per mini-batch, no `stats * scale` launch per mini-batch
+        import inspect
+        self._accumulates = 'stats_accum' in inspect.signature(ac.ppo_minibatch).parameters
+        self._acc = None
 
     def set_epoch(self, locals_: Sequence[np.ndarray]):
         """this rank's sample indices of every mini-batch of the epoch: ONE upload; `run` hands device views of it to the
@@ -146,6 +151,8 @@ class _DeviceRunner:
         for p in self.ac.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
+        if self._accumulates:
+            self._acc = torch.zeros(6, dtype=torch.float64, device=self.dev)  # (on the current stream, ahead of the waits below)
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(self.dev))  # (also orders the index upload before the gathers)
 
@@ -166,20 +173,31 @@ class _DeviceRunner:
     def run(self, mb_index: int, local: np.ndarray, scale: float) -> torch.Tensor:
         if len(local) == 0:  # this rank's slice of a small remainder mini-batch
             return torch.zeros(6, dtype=torch.float64, device=self.dev)
+        kw = {'stats_accum': self._acc} if self._accumulates else {}
         if not self.streams:
-            stats = self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale)
+            stats = self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale, **kw)
+            if self._accumulates:
+                return None
             return stats if scale == 1.0 else stats * scale
         slot = mb_index % len(self.streams)
         st = self.streams[slot]
         with torch.cuda.stream(st):  # gather and step on the mini-batch's own stream: no cross-stream hand-off
             mb = self._minibatch(mb_index, local)
-            stats = self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale, slot=slot) * scale
+            stats = self.ac.ppo_minibatch(mb, *self.hp, loss_scale=scale, slot=slot, **kw)
+            if not self._accumulates:
+                stats = stats * scale
+        if self._accumulates:
+            return None
         stats.record_stream(torch.cuda.current_stream(self.dev))
         return stats
 
     def end_epoch(self):
         for st in self.streams:
             torch.cuda.current_stream(self.dev).wait_stream(st)
+
+    def accumulated(self) -> Optional[torch.Tensor]:
+        """sum over this rank's mini-batches of (share x statistics), where the agent accumulated it on the device"""
+        return self._acc if self._accumulates else None
 
 
 class _AutogradRunner:
@@ -194,6 +212,9 @@ class _AutogradRunner:
 
     def begin_epoch(self):
         pass
+
+    def accumulated(self):
+        return None
 
     def run(self, mb_index: int, local: np.ndarray, scale: float) -> torch.Tensor:
         if len(local) == 0:  # mean over zero samples is NaN: an empty slice contributes nothing
@@ -255,10 +276,13 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
         runner.end_epoch()
         # mean of mini-batch means (ppo.py:92-95): every entry is (share x the mean over its samples); over all ranks the
         # entries of one mini-batch add up to its mean
+        batch_stats = [st for st in batch_stats if st is not None]
+        stats = torch.zeros(6, dtype=torch.float64, device=runner.dev)
         if batch_stats:
-            stats = torch.stack(batch_stats).sum(dim=0) / len(batches)
-        else:
-            stats = torch.zeros(6, dtype=torch.float64, device=runner.dev)
+            stats = stats + torch.stack(batch_stats).sum(dim=0)
+        if runner.accumulated() is not None:
+            stats = stats + runner.accumulated()
+        stats = stats / max(len(batches), 1)
         if dist is not None:
             dist.all_reduce(stats)
             for p in ac.parameters():

@@ -123,6 +123,52 @@ def test_train_loop_matches_oracle_loop(built_lib):
         assert d < 1e-4, (k, d)  # two Adam steps of lr 3e-4
 
 
+def test_graph_step_equals_stream_launches(built_lib):
+    """mg_cov_ppo_step as ONE updated hipGraph launch == the same step as ~27 stream launches: statistics, step outputs and
+    gradient of single mini-batches of DIFFERENT ragged sizes replayed through the same cached graph (every replay updates all
+    kernel nodes: grids and arguments follow TA / TE), and theta after two epochs of ppo.train (three mini-batches in flight,
+    one graph per stream slot) to the run-to-run reproducibility of the float atomics (2e-5)."""
+    from molgym_amd import ppo
+    ac, ref, cfg = make_pair('cfg2', seed=24)
+    sizes = (24, 31, 9, 24)
+    batches = []
+    for k, B in enumerate(sizes):
+        d = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=40 + k)
+        batches.append(ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret']))
+    for b in batches:  # several sizes through ONE cached graph (slot 0)
+        res = {}
+        for mode in (False, True):
+            ac.theta.grad = torch.zeros_like(ac.theta)
+            acc = torch.zeros(6, dtype=torch.float64, device='cuda')
+            stats = ac.ppo_minibatch(b, 0.2, 0.5, 0.01, loss_scale=0.5, stats_accum=acc, graph=mode)
+            torch.cuda.synchronize()
+            assert ac.last_step_used_graph == mode
+            res[mode] = (stats.clone(), ac._last_out.clone(), ac.theta.grad.clone(), acc.clone())
+        (s0, o0, g0, a0), (s1, o1, g1, a1) = res[False], res[True]
+        assert torch.equal(s0, s1) and torch.equal(o0, o1)       # forward + loss: no atomics, bit for bit
+        assert torch.allclose(a1, 0.5 * s1, rtol=1e-14, atol=0)  # the epoch accumulator got share x statistics
+        assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
+    # the training loop, both ways
+    data = make_batch(60, cfg['canvas_size'], cfg['zs'], seed=50)
+    theta0 = ac.theta.detach().clone()
+    out = {}
+    for mode in (False, True):
+        with torch.no_grad():
+            ac.theta.copy_(theta0)
+        ac.use_graphs = mode
+        opt = torch.optim.Adam(ac.parameters(), lr=3e-4)
+        np.random.seed(6)
+        info = ppo.train(ac, opt, data, mini_batch_size=16, clip_ratio=0.2, target_kl=1e9, vf_coef=0.5, entropy_coef=0.01,
+                         gradient_clip=0.5, max_num_steps=2)
+        assert ac.last_step_used_graph == mode
+        out[mode] = (ac.theta.detach().clone(), info)
+    ac.use_graphs = True
+    d = (out[True][0] - out[False][0]).abs().max().item()
+    assert d <= 2e-5 * out[False][0].abs().max().item(), d
+    for k in ppo.KEYS:
+        assert abs(out[True][1][k] - out[False][1][k]) <= 1e-6 * max(1.0, abs(out[False][1][k])), k
+
+
 def test_minibatches_in_flight_accumulate_like_sequential(built_lib):
     """three mini-batches on three HIP streams (own workspaces, atomic accumulation) == the sequential sum"""
     ac, ref, cfg = make_pair('cfg2', seed=23)

@@ -30,7 +30,10 @@ else:
     d = make_batch(n, cfg['canvas_size'], cfg['zs'], seed=0)
 data = {'obs': d['obs'], 'act': d['act'], 'logp': d['logp'], 'adv': d['adv'], 'ret': d['ret']}
 opt = torch.optim.Adam(ac.parameters(), lr=1e-5)
-for rep in range(3):
+modes = [None] if name == 'internal' else [False, True, False, True]
+for rep, mode in enumerate(modes if len(sys.argv) <= 5 else [bool(int(sys.argv[5]))] * 3):
+    if mode is not None:
+        ac.use_graphs = mode  # ppo_minibatch as one updated hipGraph launch (True) or ~27 stream launches (False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     info = ppo.train(ac, opt, data, mini_batch_size=mb, clip_ratio=0.2, target_kl=1e9, vf_coef=0.5, entropy_coef=0.01,
@@ -38,5 +41,5 @@ for rep in range(3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = info['num_opt_steps']
-    print(f'{name}: rollout {n}, mini-batch {mb}: {steps} epochs in {dt * 1e3:.1f} ms -> {dt / max(steps, 1) / (n / mb) * 1e3:.3f} ms per '
+    print(f'{name} [graph={mode}]: rollout {n}, mini-batch {mb}: {steps} epochs in {dt * 1e3:.1f} ms -> {dt / max(steps, 1) / (n / mb) * 1e3:.3f} ms per '
           f'mini-batch, {n * steps / dt:.0f} samples/s (prepare_rollout + gathers + norm / clip / Adam included)')
