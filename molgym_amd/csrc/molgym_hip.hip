@@ -3,10 +3,10 @@
 #include <mutex>
 #include "state.inc"
 #include "level0.inc"
+#include "edge_level.inc"
 #include "sampling.inc"
 #include "heads_fused.inc"
 #include "backward.inc"
-#include "ppo.inc"
 #include "internal.inc"
 #include "dists.inc"
 #include "canvas.inc"
@@ -199,7 +199,8 @@ struct SampleCtx {
 // actions is read-only unless smp != nullptr, in which case the sub-actions are drawn in place as the heads run.
 static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
                             const float* bags, float* actions, const float* leb, void* ws, size_t ws_bytes,
-                            float* out, void* stream, const SampleCtx* smp) {
+                            float* out, void* stream, const SampleCtx* smp, const PpoLossArgs* loss = nullptr,
+                            bool* loss_fused = nullptr) {
   PLayout P;
   int rc = build_layout(c, &P);
   if (rc) return rc;
@@ -335,7 +336,23 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   }
   for (int k = fused0 ? 1 : 0; k < 3 && TA > 0; ++k) {
     // --- edge level k (cormorant EdgeLevel: DotMatrix, cat-mix, soft mask) ---
-    if (k == 0) {
+    const bool fusedE = k >= 1 && edge_level_fused(fused0, N);
+    if (fusedE) {
+      ELArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      for (int l = 0; l < 5; ++l) {
+        ea.A[l] = w.A[k][l]; ea.row[l] = w.cat_e[k][l];
+        ea.out[l] = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+        ea.mb[l] = w.edge[k][l].mb;
+        if (w.ld_e[k][l] != EL_K || w.edge[k][l].ldb != w.edge[k][0].ldb || w.edge[k][l].K != EL_K)
+          MG_FAIL(MG_EINVAL, "edge-level kernel: unexpected row layout");
+      }
+      ea.ld_row = EL_K; ea.ld_out = (k < 2) ? w.ld_e[k + 1][0] : 2 * CH; ea.ldb = w.edge[k][0].ldb;
+      ea.em = w.em; ea.Acm = w.Acm[k]; ea.TA = TA; ea.N = N;
+      ProfScope prof(s, "k_edge_level");
+      hipLaunchKernelGGL(k_edge_fwd, dim3(TA), dim3(EL_T), el_fwd_lds_bytes(N), s, ea, w.L);
+      LAUNCH_CHECK();
+    } else if (k == 0) {
       hipLaunchKernelGGL(k_dot0, dim3((TE * CH + 255) / 256), dim3(256), 0, s, TE, w.L, w.A0, w.cat_e[0][0],
                          w.ld_e[0][0], w.dcol[0]);
     } else {
@@ -357,7 +374,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     }
     LAUNCH_CHECK();
     if (k == 0) side_join(s);  // radial columns of every level are in place
-    if (k == 0 || !w.shared_dot) {
+    if (fusedE) {
+    } else if (k == 0 || !w.shared_dot) {
       GemmG ge[5];
       for (int l = 0; l < 5; ++l) {
         float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
@@ -426,8 +444,9 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     make_head_args(c, P, w, theta, &HD, &HW, &HB);
     ProfScope prof(s, "k_heads_fwd");
     hipLaunchKernelGGL(k_heads_fwd, dim3(B, 3), dim3(256), head_smem_bytes(nlat, P.nlatE), s, HD, w.L, HW, HB, g_cgtab[cur_device()], A3, actions,
-                       bags, leb, out);
+                       bags, leb, out, loss ? *loss : PpoLossArgs{});
     LAUNCH_CHECK();
+    if (loss && loss_fused) *loss_fused = true;
     return MG_OK;
   }
   if (TA > 0) {
@@ -622,12 +641,19 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
                                float* grad_theta, int32_t graph_slot, int32_t* used_graph, void* stream) {
   if (!c || !out || !gout || !stats || !grad_theta) MG_FAIL(MG_EINVAL, "mg_cov_ppo_step: null argument");
   hipStream_t s = (hipStream_t)stream;
+  static int fuse_loss = -1;
+  if (fuse_loss < 0) { const char* e = getenv("MG_FUSED_LOSS"); fuse_loss = e ? atoi(e) : 1; }
   auto run = [&]() -> int {
-    int rc = cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream, nullptr);
+    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum};
+    bool fused = false;
+    int rc = cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream, nullptr,
+                              fuse_loss ? &la : nullptr, &fused);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
-                       entropy_coef, stats, gout, loss_scale, stats_accum);
-    LAUNCH_CHECK();
+    if (!fused) {  // (staged heads: the loss as its own launch)
+      hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
+                         entropy_coef, stats, gout, loss_scale, stats_accum);
+      LAUNCH_CHECK();
+    }
     return mg_cov_backward(c, theta, pos, charges, bags, actions, leb, ws, ws_bytes, gout, grad_theta, stream);
   };
   if (used_graph) *used_graph = 0;
