@@ -57,8 +57,8 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step.  */
-#define MG_ABI_VERSION 3
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated.  */
+#define MG_ABI_VERSION 4
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
@@ -237,6 +237,21 @@ int mg_grad_norm_clip(int64_t n, float* grad, float max_norm, float* norm_out, v
 int mg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int32_t maximize,
                  void* stream);
+/* the same update, skipped entirely when *skip_flag != 0 (device int; may be null) */
+int mg_adam_step_gated(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                       double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int32_t maximize,
+                       const int32_t* skip_flag, void* stream);
+
+/* ---- end of a PPO epoch on the device (molgym/ppo.py:133-146: KL test, gradient norm, clip) --------------------------------
+ * stats_accum[6] f64 = sum over the epoch's mini-batches of (share x statistics) (mg_cov_ppo_step); inv_num_minibatches = 1 / M.
+ * rec[8] f64 <- {policy_loss, entropy_loss, vf_loss, total_loss, approx_kl, clip_fraction} means, the PRE-clip gradient norm,
+ * and 1.0 if the update loop has stopped (this epoch's approx_kl > kl_limit, or an earlier epoch's was): the reference breaks
+ * BEFORE the optimizer step in that case (ppo.py:139-141).  *stop_flag (device int, zero before the first epoch) latches; the
+ * clip (grad *= min(1, max_norm / (norm + 1e-6)), max_norm > 0) is applied only while it is clear, and mg_adam_step_gated with
+ * the same flag does nothing once it is set -- so the host may issue the next epoch without waiting for this one and read
+ * `rec` late.  scratch: 1 float.                                                                                          */
+int mg_ppo_epoch_end(int64_t n, float* grad, float max_norm, const double* stats_accum, double inv_num_minibatches,
+                     double kl_limit, double* rec, int32_t* stop_flag, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,9 @@ SYMBOLS = {
     'mg_canvas_append': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P, _P, _P, _P, _P, _P]),
     'mg_adam_step': (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_int64, C.c_int32, _P]),
+    'mg_adam_step_gated': (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_int64, C.c_int32, _P, _P]),
+    'mg_ppo_epoch_end': (C.c_int, [C.c_int64, _P, C.c_float, _P, C.c_double, C.c_double, _P, _P, _P, _P]),
     'mg_gather_rows': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P, C.c_int32, _P]),
     'mg_cov_check': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P]),
     'mg_cov_head_outputs': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P, _P]),
@@ -71,7 +74,7 @@ _variants = {}
 DEFAULT_CHANNELS = (10, 4)  # num_channels_hidden, num_channels_per_element of the default build (arg_parser.py:55-60)
 
 
-ABI_VERSION = 3  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+ABI_VERSION = 4  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
 
 
 def _bind(path):

@@ -118,13 +118,8 @@ class FlatThetaAgent(AbstractActorCritic):
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.theta.device).cuda_stream)
 
-    def adam_step(self, optimizer) -> bool:
-        """optimizer.step() (ppo.py:145) for a plain torch.optim.Adam over the flat theta as ONE HIP launch (mg_adam_step)
-        on the optimizer's own state tensors, which are created exactly as torch creates them -- so state_dict(), learning-
-        rate schedulers (their step counter is advanced here) and a later optimizer.step() see nothing unusual; an
-        optimizer with step hooks is left to optimizer.step().  Returns False (nothing done) for anything else:
-        another optimizer class, several parameter groups / tensors, fused / capturable / differentiable variants."""
-        from .. import _lib
+    def adam_supported(self, optimizer) -> bool:
+        """whether `adam_step` takes this optimizer (a plain torch.optim.Adam over the single flat theta, no step hooks)"""
         if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
             return False
         # step hooks registered on the optimizer (or globally) must run: leave those cases to optimizer.step()
@@ -140,6 +135,24 @@ class FlatThetaAgent(AbstractActorCritic):
             return False
         if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse or not p.grad.is_contiguous():
             return False
+        if g['amsgrad'] and len(optimizer.state[p]) and 'max_exp_avg_sq' not in optimizer.state[p]:
+            return False
+        return True
+
+    def adam_step(self, optimizer, skip_flag: Optional[torch.Tensor] = None) -> bool:
+        """optimizer.step() (ppo.py:145) for a plain torch.optim.Adam over the flat theta as ONE HIP launch (mg_adam_step)
+        on the optimizer's own state tensors, which are created exactly as torch creates them -- so state_dict(), learning-
+        rate schedulers (their step counter is advanced here) and a later optimizer.step() see nothing unusual; an
+        optimizer with step hooks is left to optimizer.step().  Returns False (nothing done) for anything else:
+        another optimizer class, several parameter groups / tensors, fused / capturable / differentiable variants.
+        `skip_flag` (device int32, optional): the launch does nothing when it is non-zero (mg_adam_step_gated: the KL test of
+        ppo.train taken on the device); the optimizer's step counter is advanced either way -- the caller takes the skipped
+        steps back (`adam_unstep`) once it has read the flag."""
+        from .. import _lib
+        if not self.adam_supported(optimizer):
+            return False
+        g = optimizer.param_groups[0]
+        p = self.theta
         st = optimizer.state[p]
         if len(st) == 0:  # torch.optim.Adam._init_group
             st['step'] = torch.tensor(0.0, dtype=torch.float64 if torch.get_default_dtype() == torch.float64 else torch.float32)
@@ -154,16 +167,39 @@ class FlatThetaAgent(AbstractActorCritic):
         beta1, beta2 = g['betas']
         ptr = lambda t: C.c_void_p(t.data_ptr())
         with self._guard():
-            _lib.check(_lib.lib().mg_adam_step(p.numel(), ptr(p.data), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']),
-                                               ptr(st['max_exp_avg_sq']) if g['amsgrad'] else None, float(g['lr']),
-                                               float(beta1), float(beta2), float(g['eps']), float(g['weight_decay']), step,
-                                               1 if g.get('maximize') else 0, self._s()))
+            _lib.check(_lib.lib().mg_adam_step_gated(p.numel(), ptr(p.data), ptr(p.grad), ptr(st['exp_avg']), ptr(st['exp_avg_sq']),
+                                                     ptr(st['max_exp_avg_sq']) if g['amsgrad'] else None, float(g['lr']),
+                                                     float(beta1), float(beta2), float(g['eps']), float(g['weight_decay']), step,
+                                                     1 if g.get('maximize') else 0,
+                                                     None if skip_flag is None else ptr(skip_flag), self._s()))
         # what a learning-rate scheduler's wrapper of optimizer.step() would have recorded (lr_scheduler.py: `_step_count`,
         # `_opt_called`; the scheduler warns about "lr_scheduler.step() before optimizer.step()" otherwise)
         if hasattr(optimizer, '_step_count'):
             optimizer._step_count += 1
         optimizer._opt_called = True
         return True
+
+    def adam_unstep(self, optimizer, count: int) -> None:
+        """take back `count` optimizer steps whose launches the device-side gate skipped (step counters only: the parameters
+        and moments were never touched)"""
+        if count <= 0:
+            return
+        st = optimizer.state[self.theta]
+        st['step'] -= count
+        if hasattr(optimizer, '_step_count'):
+            optimizer._step_count -= count
+
+    def ppo_epoch_end(self, max_norm: float, stats_accum: torch.Tensor, num_minibatches: int, kl_limit: float,
+                      rec: torch.Tensor, stop_flag: torch.Tensor) -> None:
+        """mg_ppo_epoch_end: KL test, gradient norm and clip of one PPO epoch on the device (ppo.py:133-144); `rec` (8 float64)
+        receives the epoch's statistics, the pre-clip norm and the state of the latching `stop_flag` (int32)."""
+        from .. import _lib
+        scratch = torch.empty(1, dtype=torch.float32, device=self.theta.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        with self._guard():
+            _lib.check(_lib.lib().mg_ppo_epoch_end(self.theta.numel(), ptr(self.theta.grad), float(max_norm), ptr(stats_accum),
+                                                   1.0 / max(int(num_minibatches), 1), float(kl_limit), ptr(rec), ptr(stop_flag),
+                                                   ptr(scratch), self._s()))
 
     def grad_norm_clip(self, max_norm: float = 0.0) -> torch.Tensor:
         """||theta.grad||_2 as a 1-element device tensor (util.compute_gradient_norm, tools/util.py:61-69) and, if

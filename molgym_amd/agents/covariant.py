@@ -333,6 +333,33 @@ class CovariantAC(FlatThetaAgent):
             for cfg, ws in pending.values():
                 self._chk(self._L().mg_cov_check(C.byref(cfg), _ptr(ws), ws.numel(), self._s()))
 
+    def input_flags_async(self) -> Optional[torch.Tensor]:
+        """the list-build flags check_inputs() would read, as ONE pinned host tensor filled by asynchronous copies on the current
+        stream (one int per workspace slot used since the last check; None if there is nothing to check): the caller waits for
+        an event it records behind this call and hands the tensor to `raise_input_flags` -- ppo.train's run-ahead loop never
+        drains the stream for the check."""
+        pending = list((self.__dict__.get('_unchecked') or {}).values())
+        self._unchecked = {}
+        if not pending:
+            return None
+        host = torch.empty(len(pending), dtype=torch.int32).pin_memory()
+        for k, (cfg, ws) in enumerate(pending):
+            off, cnt = C.c_int64(), C.c_int64()
+            self._chk(self._L().mg_cov_workspace_lookup(C.byref(cfg), b'err', C.byref(off), C.byref(cnt)))
+            host[k:k + 1].copy_(ws.view(torch.int32)[off.value:off.value + 1], non_blocking=True)
+        return host
+
+    @staticmethod
+    def raise_input_flags(flags: Optional[torch.Tensor]) -> None:
+        for flag in ([] if flags is None else flags.tolist()):
+            if flag == 1:
+                raise RuntimeError('molgym_hip error -1: charges: the real atoms of a canvas must be compacted to the front '
+                                   '(a padding slot precedes an atom)')
+            if flag == 2:
+                raise RuntimeError('molgym_hip error -1: cfg.TA / cfg.TE do not match the atom counts in charges')
+            if flag != 0:
+                raise RuntimeError(f'molgym_hip error -1: list build reported error {flag}')
+
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0, stats_accum: Optional[torch.Tensor] = None,
                       graph: Optional[bool] = None) -> torch.Tensor:

@@ -254,6 +254,78 @@ def shard_epoch(batches: List[np.ndarray], rank: int, world: int) -> List[Tuple[
     return work
 
 
+def _train_runahead(ac, optimizer, runner, num_samples: int, mini_batch_size: int, target_kl: float, gradient_clip: float,
+                    max_num_steps: int, infos: dict) -> int:
+    """The epochs of `train` WITHOUT a host round trip per epoch.  The reference reads the epoch's mean KL on the host, breaks
+    before the optimizer step when it is over 1.5 x target_kl, clips and steps otherwise (ppo.py:133-146) -- a synchronisation
+    per epoch that drains the three mini-batches in flight and leaves the GPU idle until the next epoch's first launches arrive
+    (~0.6 ms of a 3.7 ms epoch on the SF6 rollout).  Here the test, the norm and the clip run on the device
+    (`ac.ppo_epoch_end`), the Adam launch is gated by the latching stop flag, and the host issues epoch i + 1 BEFORE it reads
+    epoch i's record: the GPU always has an epoch queued.  Same result as the synchronous loop: once an epoch's KL is over the
+    limit nothing updates theta any more; the one epoch issued speculatively behind it is discarded (its optimizer-step counter
+    is taken back, the numpy RNG is put back to where the reference's loop would have left it)."""
+    dist, rank, world = _dist()
+    dev = runner.dev
+    stop = torch.zeros(1, dtype=torch.int32, device=dev)
+    recs_dev = torch.zeros(max_num_steps, 8, dtype=torch.float64, device=dev)
+    recs_host = torch.zeros(max_num_steps, 8, dtype=torch.float64).pin_memory()
+    events, rng_states, keep = [], [], []
+    flags, issued = None, 0
+    for p in ac.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    for i in range(max_num_steps):
+        rng_states.append(np.random.get_state())
+        for p in ac.parameters():
+            p.grad.zero_()  # (optimizer.zero_grad(), in place: the launches of the epoch in flight hold the tensor's address)
+        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank)
+        slices = shard_epoch(batches, rank, world)
+        runner.set_epoch([sl for sl, _ in slices])
+        runner.begin_epoch()
+        for mb_index, (sl, share) in enumerate(slices):
+            runner.run(mb_index, sl, share)
+        runner.end_epoch()
+        acc = runner.accumulated()
+        keep.append(acc)  # (written by the mini-batches' own streams: alive until the loop has drained)
+        if dist is not None:
+            dist.all_reduce(acc)
+            for p in ac.parameters():
+                dist.all_reduce(p.grad)
+        ac.ppo_epoch_end(gradient_clip, acc, len(batches), 1.5 * target_kl, recs_dev[i], stop)
+        ac.adam_step(optimizer, skip_flag=stop)
+        recs_host[i].copy_(recs_dev[i], non_blocking=True)
+        if i == 0 and hasattr(ac, 'input_flags_async'):
+            flags = ac.input_flags_async()  # inconsistent inputs raise at the first look below instead of training on garbage
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+        issued += 1
+        if i >= 1:  # epoch i is queued: now look at epoch i - 1
+            events[i - 1].synchronize()
+            if flags is not None:
+                ac.raise_input_flags(flags)
+                flags = None
+            if recs_host[i - 1, 7].item() != 0.0:
+                break
+    if events:
+        events[-1].synchronize()
+    if flags is not None:
+        ac.raise_input_flags(flags)
+    stopped = [k for k in range(issued) if recs_host[k, 7].item() != 0.0]
+    num_epochs = stopped[0] if stopped else issued
+    ac.adam_unstep(optimizer, issued - num_epochs)
+    if stopped:
+        logging.debug(f'Early stopping at step {num_epochs} for reaching max KL.')
+        if issued > num_epochs + 1:  # a speculative epoch drew a permutation the reference's loop never draws
+            np.random.set_state(rng_states[num_epochs + 1])
+    if num_epochs > 0:
+        row = recs_host[num_epochs - 1].tolist()
+        infos.update(dict(zip(KEYS, row[:6])))
+        infos['grad_norm'] = row[6]
+    optimizer.zero_grad()
+    return num_epochs
+
+
 def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_ratio: float, target_kl: float,
           vf_coef: float, entropy_coef: float, gradient_clip: float, max_num_steps: int, device=None) -> dict:
     infos: Dict[str, float] = {}
@@ -266,6 +338,18 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
     flat = hasattr(ac, 'grad_norm_clip') and next(ac.parameters()).device.type == 'cuda'
     num_samples = len(data['obs'])
     num_epochs = 0
+    import os
+    runahead = device_path and flat and getattr(runner, '_accumulates', False) and hasattr(ac, 'ppo_epoch_end') and \
+        max_num_steps >= 2 and num_samples > 0 and os.environ.get('MOLGYM_RUNAHEAD', '1') != '0'
+    if runahead:
+        for p in ac.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        runahead = ac.adam_supported(optimizer)
+    if runahead:
+        num_epochs = _train_runahead(ac, optimizer, runner, num_samples, mini_batch_size, target_kl, gradient_clip,
+                                     max_num_steps, infos)
+        max_num_steps = 0  # (the synchronous loop below is skipped)
     for i in range(max_num_steps):
         optimizer.zero_grad()
         batches = _epoch_batches(num_samples, mini_batch_size, dist, rank)

@@ -169,6 +169,53 @@ def test_graph_step_equals_stream_launches(built_lib):
         assert abs(out[True][1][k] - out[False][1][k]) <= 1e-6 * max(1.0, abs(out[False][1][k])), k
 
 
+def test_runahead_epochs_equal_synchronous_loop(built_lib, monkeypatch):
+    """ppo.train with the KL test / norm / clip on the device and the next epoch issued before the previous one's record is read
+    (molgym_amd/ppo.py::_train_runahead) == the loop that synchronises every epoch like the reference (ppo.py:133-146): same
+    number of optimizer steps when the KL test fires in the middle, same theta, same statistics, same Adam step counter, and
+    the numpy RNG left where the reference's loop leaves it (the speculative epoch's permutation is taken back)."""
+    from molgym_amd import ppo
+    ac, ref, cfg = make_pair('cfg2', seed=25)
+    data = make_batch(48, cfg['canvas_size'], cfg['zs'], seed=60)
+    data['logp'] = data['logp'] * 0 + ac.step(data['obs'], data['act'])['logp'].detach().double().cpu().numpy()
+    theta0 = ac.theta.detach().clone()
+
+    def run(mode, target_kl, max_steps=6):
+        monkeypatch.setenv('MOLGYM_RUNAHEAD', mode)
+        with torch.no_grad():
+            ac.theta.copy_(theta0)
+        ac.theta.grad = None
+        opt = torch.optim.Adam(ac.parameters(), lr=3e-4)
+        np.random.seed(7)
+        info = ppo.train(ac, opt, data, mini_batch_size=16, clip_ratio=0.2, target_kl=target_kl, vf_coef=0.5, entropy_coef=0.01,
+                         gradient_clip=0.5, max_num_steps=max_steps)
+        st = opt.state[ac.theta]
+        return info, ac.theta.detach().clone(), float(st['step']) if len(st) else 0.0, np.random.get_state()[1].copy()
+
+    # the KL after each epoch of this run (synchronous loop, no early stop) picks a limit that fires in the middle
+    kls = [run('0', 1e9, k)[0]['approx_kl'] for k in (1, 2, 3, 4)]
+    limit = None
+    for k in range(1, 4):  # a limit between |kl| of epochs k-1 and k, well away from both
+        lo, hi = max(kls[:k]), kls[k]
+        if hi > 0 and hi > 3 * max(lo, 1e-9):
+            limit = (max(lo, 0.0) * hi)**0.5 if lo > 0 else hi / 2
+            expect = k
+            break
+    assert limit is not None, kls
+    for target in (limit / 1.5, 1e9):
+        i0, t0, s0, r0 = run('0', target)
+        i1, t1, s1, r1 = run('1', target)
+        assert i0['num_opt_steps'] == i1['num_opt_steps'] and s0 == s1
+        if target < 1e8:
+            assert i0['num_opt_steps'] == expect, (i0['num_opt_steps'], expect, kls)
+        assert np.array_equal(r0, r1)
+        # (up to six Adam steps: the run-to-run noise of the float atomics, which Adam turns into O(lr) differences on entries
+        # whose gradient is ~0, grows with the number of steps; two steps hold 2e-5 in the tests above)
+        assert (t0 - t1).abs().max().item() <= 1e-4 * t0.abs().max().item()
+        for k in ppo.KEYS + ('grad_norm', ):
+            assert abs(i0[k] - i1[k]) <= 1e-5 * max(1.0, abs(i0[k])), k
+
+
 def test_minibatches_in_flight_accumulate_like_sequential(built_lib):
     """three mini-batches on three HIP streams (own workspaces, atomic accumulation) == the sequential sum"""
     ac, ref, cfg = make_pair('cfg2', seed=23)
