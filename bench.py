@@ -436,6 +436,10 @@ def main():
                        'median_ms_per_step': median_ms,
                        'samples_per_s_at_median': None if median_ms is None else total_samples / (median_ms * 1e-3),
                        'host_enqueue_ms_per_step': t_issued / args.steps * 1e3,
+                       # how the step reaches the GPU: mg_cov_ppo_step records its kernel launches and issues them as ONE
+                       # hipGraph launch whose nodes are updated in place (include/molgym_hip.h); MG_GRAPH=0: plain stream launches
+                       'issued_as_one_graph_launch': bool(getattr(ac, 'last_step_used_graph', False)),
+                       'kernel_launches_per_step': int(ac._L().mg_cov_step_launches()) or None,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,
                        'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world),

@@ -57,8 +57,8 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated.  */
-#define MG_ABI_VERSION 4
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches.  */
+#define MG_ABI_VERSION 5
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
@@ -213,6 +213,9 @@ int mg_cov_ppo_step(const mg_cov_cfg* cfg, const float* theta, const float* pos,
                     const double* old_logp, const double* adv, const double* ret, double clip_ratio, double vf_coef,
                     double entropy_coef, double loss_scale, float* out, float* gout, double* stats, double* stats_accum,
                     float* grad_theta, int32_t graph_slot, int32_t* used_graph_host, void* stream);
+
+/* kernel launches (= graph nodes) of the last mg_cov_ppo_step this host thread issued in graph form; 0 if none (measurement) */
+int mg_cov_step_launches(void);
 
 /* ---- GAE-lambda over concatenated trajectories (buffer.py:74-82) ------------------ */
 /* path_off [P+1] i32 start offsets; rew, val [T] f64; last_val [P] f64.

@@ -682,6 +682,9 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
   return run();
 }
 
+// kernel launches the last RECORDED mg_cov_ppo_step of this host thread consisted of (0 if none was recorded): bench.py prints it
+extern "C" int mg_cov_step_launches(void) { return (int)g_rec.recs.size(); }
+
 #ifdef MG_TS
 // debug builds only (tools/ts_heads.sh): read the phase timestamps (100 MHz ticks) and choose the stamped workgroup
 extern "C" int mg_debug_ts(unsigned long long* out, int block) {
