@@ -336,6 +336,8 @@ def main():
         elapsed = t.item()
     if not torch.isfinite(stats).all():
         raise SystemExit('non-finite loss statistics')
+    step_used_graph = bool(getattr(ac, 'last_step_used_graph', False))  # (the live roofline leg below runs eagerly: events per kernel)
+    step_launches = int(ac._L().mg_cov_step_launches()) or None
     dist_info = None
     if use_dist:
         # evidence for the scaling record: how many RCCL ranks there were, which device each drove, and that after the last
@@ -438,8 +440,8 @@ def main():
                        'host_enqueue_ms_per_step': t_issued / args.steps * 1e3,
                        # how the step reaches the GPU: mg_cov_ppo_step records its kernel launches and issues them as ONE
                        # hipGraph launch whose nodes are updated in place (include/molgym_hip.h); MG_GRAPH=0: plain stream launches
-                       'issued_as_one_graph_launch': bool(getattr(ac, 'last_step_used_graph', False)),
-                       'kernel_launches_per_step': int(ac._L().mg_cov_step_launches()) or None,
+                       'issued_as_one_graph_launch': step_used_graph,
+                       'kernel_launches_per_step': step_launches,
                        'step_tflops_dense_convention': f_dense * value / 1e12,
                        'step_tflops_ragged': f_ragged * value / 1e12,
                        'frac_f32_peak_dense_convention': f_dense * value / 1e12 / (PEAK_F32_TFLOPS * world),
