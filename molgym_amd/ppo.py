@@ -128,7 +128,9 @@ class _DeviceRunner:
         self.dev = next(ac.parameters()).device
         self.streams = []
         if self.dev.type == 'cuda' and len(data['obs']) > mini_batch_size:
-            self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(3)]
+            import os
+            nstreams = max(1, min(8, int(os.environ.get('MOLGYM_TRAIN_STREAMS', '3'))))  # (8 = the library's graph slots)
+            self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstreams)]
         # agents whose ppo_minibatch adds (share x statistics) into an epoch accumulator on the device (CovariantAC: inside the
         # loss kernel): no tensor per mini-batch, no `stats * scale` launch per mini-batch
         import inspect

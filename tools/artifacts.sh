@@ -24,5 +24,6 @@ tail -1 $out/bench_$config.json | cut -c1-2500
 timeout -k 5 300 rocprofv3 --kernel-trace -d $out -o prof_$config -- python bench.py --config $config --steps $steps --warmup $warm --no-cpu-baseline --no-epoch-overlap > $out/bench_prof_$config.log 2>&1
 # launches in the trace: warm-up + timed steps + the 20 iterations of the live roofline leg
 python tools/rocpd_summary.py $out/prof_${config}_results.db $out/kernel_stats_$config.csv $((steps + warm + 20)) > /dev/null && head -14 $out/kernel_stats_$config.csv && tail -1 $out/kernel_stats_$config.csv
-python tools/rocpd_timeline.py $out/prof_${config}_results.db $marker > $out/timeline_$config.txt 2>&1
+# a TIMED step (the trace ends with the 20 event-bracketed steps of the live roofline leg)
+python tools/rocpd_timeline.py $out/prof_${config}_results.db $marker 22 > $out/timeline_$config.txt 2>&1
 rm -f $out/*_results.db

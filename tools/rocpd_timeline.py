@@ -1,6 +1,8 @@
 """Timeline of the LAST full step in a rocprofv3 --kernel-trace rocpd database: one line per kernel with its start
 offset, duration, gap to the previous kernel's end on any queue, and the queue.  Usage: rocpd_timeline.py <db> [marker]
-The step is taken between the last two launches of `marker` (default k_prep_counts, once per forward)."""
+The step is taken between two consecutive launches of `marker` (default k_prep_counts, once per forward): the last two, or --
+third argument `skip` -- the pair `skip` steps before the end (bench.py ends with 20 eagerly issued steps whose kernels are
+bracketed by HIP events for the live roofline figures: their gaps are the events', not the step's)."""
 import sqlite3
 import sys
 
@@ -11,9 +13,10 @@ def main():
     rows = list(db.execute('select name, start, end, queue_id, grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z), '
                            'lds_size, vgpr_count from kernels order by start'))
     marks = [i for i, r in enumerate(rows) if r[0].startswith(marker)]
-    if len(marks) < 2:
-        raise SystemExit('marker not found twice')
-    i0, i1 = marks[-2], marks[-1]
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if len(marks) < 2 + skip:
+        raise SystemExit('marker not found often enough')
+    i0, i1 = marks[-2 - skip], marks[-1 - skip]
     t0 = rows[i0][1]
     last_end = t0
     busy = 0
