@@ -115,13 +115,15 @@ def step_hbm(config, ms_per_step):
 def family_rooflines(per_step_ms, natoms, num_zs):
     """`roofline.families`: per kernel family {flops per step (algorithmic, ragged), us per step (live HIP events around the
     family's launches, summed), achieved TFLOP/s, fraction of the f32 peak}.  The families are the library's timing spans:
-    k_gemm_rows (every forward product and input adjoint of the encoder: row / column / shared-input GEMM launches),
-    k_gemm_dw (every weight gradient), k_heads_fwd / k_heads_bwd, k_dot (DotMatrix and its adjoint), and the two CG kernels."""
+    k_gemm_rows (forward products and input adjoints issued as GEMM launches), k_gemm_dw (every weight gradient), k_heads_fwd /
+    k_heads_bwd, the two CG kernels and, on the small-batch path, k_level0 / k_edge_level (the fused per-atom kernels; see
+    tools/flops.py::family_flops for what is counted where).  The spans include the HIP events that bracket every launch of
+    the family (a few us per launch on families of many short launches): fractions are lower bounds."""
     import sys
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from tools.flops import family_flops
-    fl = family_flops(natoms, num_zs)
+    fl = family_flops(natoms, num_zs, fused_small='k_level0' in per_step_ms)
     fl['k_catbuild_mfma'] = catbuild_flops(natoms, False)[1] * 2      # executed (sparse-table) count, two levels
     fl['k_catbuild_bwd_mfma'] = catbuild_flops(natoms, True)[1] * 2
     out = {}

@@ -73,27 +73,30 @@ def step_flops(natoms_list, num_zs):
     return 3 * sum(forward_flops(int(n), num_zs) for n in natoms_list)
 
 
-def family_flops(natoms_list, num_zs):
+def family_flops(natoms_list, num_zs, fused_small=False):
     """Algorithmic flops of ONE fwd+bwd step (ragged: real atoms only) per kernel FAMILY -- the names are the library's
     live-timing spans (mg_profile_report).  Every dense product is counted once forward, once for the adjoint w.r.t. its
-    input (`k_gemm_rows`: the row / column / shared-input GEMM launches) and once for its weight gradient (`k_gemm_dw`);
-    the heads' dense layers run inside `k_heads_fwd` / `k_heads_bwd` (their weight gradients in `k_gemm_dw`)."""
+    input and once for its weight gradient (`k_gemm_dw`: always the deferred GEMM launches); the heads' dense layers run inside
+    `k_heads_fwd` / `k_heads_bwd`.  Where the forward products and input adjoints run depends on the path:
+    fused_small (the SF6-sized mini-batches: level0.inc / edge_level.inc): `k_level0` = radial Linears of all levels + DotMatrix
+    and both mixes of level 0, `k_edge_level` = DotMatrix + edge mixes of levels 1, 2, `k_gemm_rows` = the atom cat-mixes of
+    levels 1, 2 only; otherwise everything is in `k_gemm_rows` (row / column / shared-input GEMM launches) and `k_dot`."""
     co = num_zs * CE
     M = [2 * l + 1 for l in range(L + 1)]
     nlat, nlat_e = (L + 2) * co * 2, (L + 2) * CE * 2
-    out = dict(k_gemm_rows=0.0, k_gemm_dw=0.0, k_heads_fwd=0.0, k_heads_bwd=0.0, k_dot=0.0)
+    out = dict(k_gemm_rows=0.0, k_gemm_dw=0.0, k_heads_fwd=0.0, k_heads_bwd=0.0, k_dot=0.0, k_level0=0.0, k_edge_level=0.0)
     for n in natoms_list:
         n = int(n)
         radial = n * n * 3 * (L + 1) * 2 * 32 * 2 * C
-        edge_mix = dot = atom_mix = 0
+        edge_mix, dot, atom_mix = [0, 0, 0], [0, 0, 0], [0, 0, 0]
         for k in range(3):
             parts = [C] if k == 0 else [C] * 5
-            dot += n * n * sum(tt * M[l] * 8 for l, tt in enumerate(parts))
+            dot[k] = n * n * sum(tt * M[l] * 8 for l, tt in enumerate(parts))
             c_in = (0 if k == 0 else C) + sum(parts) + C
-            edge_mix += n * n * (L + 1) * c_in * C * 8
+            edge_mix[k] = n * n * (L + 1) * c_in * C * 8
             tau_cat = [3 * C, C, C, C, C] if k == 0 else [C * (2 * b + 1) for b in NBLK]
-            atom_mix += n * sum(tau_cat[l] * (co if k == 2 else C) * M[l] * 8 for l in range(L + 1))
-        enc = radial + edge_mix + atom_mix
+            atom_mix[k] = n * sum(tau_cat[l] * (co if k == 2 else C) * M[l] * 8 for l in range(L + 1))
+        enc = radial + sum(edge_mix) + sum(atom_mix)
         per_atom_mlp = n * (2 * nlat * W + 2 * W) + n * (2 * nlat * W + 2 * W * W)
         per_sample_mlp = (2 * nlat * W + 2 * W * num_zs) + (2 * nlat_e * W + 2 * W * 2 * G) + (2 * W * W + 2 * W)
         mixer_mix = sum(CE * (b + 2) * CE * M[l] * 8 for l, b in enumerate(NBLK))
@@ -101,11 +104,16 @@ def family_flops(natoms_list, num_zs):
                                      for a in range(L + 1) for b in range(L + 1))
         head_dense = per_atom_mlp + per_sample_mlp + mixer_mix
         head_other = n * co * 25 * 6 + mixer_cg + 1730 * (25 * CE * 8 + 200)
-        out['k_gemm_rows'] += 2 * enc                      # forward + input adjoint
+        if fused_small:
+            out['k_level0'] += 2 * (radial + edge_mix[0] + atom_mix[0]) + 3 * dot[0]
+            out['k_edge_level'] += 2 * (edge_mix[1] + edge_mix[2]) + 3 * (dot[1] + dot[2])
+            out['k_gemm_rows'] += 2 * (atom_mix[1] + atom_mix[2])
+        else:
+            out['k_gemm_rows'] += 2 * enc                  # forward + input adjoint
+            out['k_dot'] += 3 * sum(dot)                   # forward + two input adjoints
         out['k_gemm_dw'] += enc + head_dense               # every weight gradient
         out['k_heads_fwd'] += head_dense + head_other
         out['k_heads_bwd'] += head_dense + 2 * head_other  # input adjoints (the non-linear parts cost ~2x backward)
-        out['k_dot'] += 3 * dot                            # forward + two input adjoints
     return out
 
 
