@@ -64,6 +64,8 @@ SYMBOLS = {
     'mg_cov_ppo_step': (C.c_int, [C.POINTER(CovCfg), _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, C.c_double, C.c_double,
                                   C.c_double, C.c_double, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     'mg_cov_step_launches': (C.c_int, []),
+    'mg_int_ppo_step': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
     'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     'mg_gae': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     'mg_adv_normalize': (C.c_int, [C.c_int32, _P, _P, _P]),
@@ -75,7 +77,7 @@ _variants = {}
 DEFAULT_CHANNELS = (10, 4)  # num_channels_hidden, num_channels_per_element of the default build (arg_parser.py:55-60)
 
 
-ABI_VERSION = 5  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+ABI_VERSION = 6  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
 
 
 def _bind(path):

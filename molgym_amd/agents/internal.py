@@ -284,27 +284,34 @@ class SchNetAC(FlatThetaAgent):
         return batch
 
     def ppo_minibatch(self, batch: IntBatch, clip_ratio: float, vf_coef: float, entropy_coef: float,
-                      loss_scale: float = 1.0, slot: int = 0) -> torch.Tensor:
-        """forward + float64 PPO loss + hand-written backward on the device (ppo.py:124-131), gradients accumulated
-        into theta.grad (scaled by `loss_scale`: the data-parallel B_local / B_global); same signature as
-        CovariantAC.ppo_minibatch.  Returns the 6 loss statistics (float64 device tensor, no sync)."""
+                      loss_scale: float = 1.0, slot: int = 0, stats_accum: Optional[torch.Tensor] = None,
+                      graph: Optional[bool] = None) -> torch.Tensor:
+        """forward + float64 PPO loss + hand-written backward on the device (ppo.py:124-131) in ONE C call (mg_int_ppo_step),
+        gradients accumulated into theta.grad (scaled by `loss_scale`: the data-parallel B_local / B_global); same signature
+        and meaning as CovariantAC.ppo_minibatch: `stats_accum` receives loss_scale x statistics on the device, `graph` (default
+        on) issues the ~58 launches as one hipGraph launch whose kernel nodes are updated in place, one cached graph per `slot`.
+        Returns the 6 loss statistics (float64 device tensor, no sync)."""
         lib = _lib.lib()
-        out, ws = self._forward_nograd(batch)
+        nbytes = C.c_size_t()
+        _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
         B = batch.cfg.B
         dev = self.theta.device
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        out = torch.empty(3, B, dtype=torch.float32, device=dev)
         stats = torch.empty(6, dtype=torch.float64, device=dev)
         gout = torch.empty(3, B, dtype=torch.float32, device=dev)
+        if self.theta.grad is None:
+            self.theta.grad = torch.zeros_like(self.theta)
+        use_graph = getattr(self, 'use_graphs', True) if graph is None else graph
+        used = C.c_int32(0)
         with self._guard():
-            _lib.check(lib.mg_ppo_loss(B, _ptr(out), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio,
-                                       vf_coef, entropy_coef, _ptr(stats), _ptr(gout), self._s()))
-            if loss_scale != 1.0:
-                gout.mul_(loss_scale)
-            if self.theta.grad is None:
-                self.theta.grad = torch.zeros_like(self.theta)
-            _lib.check(lib.mg_int_backward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off),
-                                           _ptr(batch.edge_off), _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags),
-                                           _ptr(batch.actions), _ptr(ws), ws.numel(), _ptr(gout),
-                                           _ptr(self.theta.grad), self._s()))
+            _lib.check(lib.mg_int_ppo_step(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
+                                           _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions), _ptr(ws),
+                                           nbytes.value, _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef,
+                                           entropy_coef, float(loss_scale), _ptr(out), _ptr(gout), _ptr(stats), _ptr(stats_accum),
+                                           _ptr(self.theta.grad), slot if use_graph else -1, C.byref(used), self._s()))
+        self._last_ws = ws
+        self.last_step_used_graph = bool(used.value)
         return stats
 
     def _ws_view(self, cfg, ws: torch.Tensor, name: str) -> torch.Tensor:

@@ -669,7 +669,7 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
     g_rec.end();
     if (rc) return rc;
     if (!g_rec.unsupported && !g_rec.recs.empty()) {
-      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][graph_slot], s);
+      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][0][graph_slot], s);
       if (e == hipSuccess) {
         if (used_graph) *used_graph = 1;
         return MG_OK;
@@ -677,6 +677,43 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
       (void)hipGetLastError();
       static bool warned = false;
       if (!warned) { fprintf(stderr, "molgym_hip: graph launch failed (%s); running eagerly\n", hipGetErrorString(e)); warned = true; }
+    }
+  }
+  return run();
+}
+
+// the same for the internal-coordinate (SchNet) actor-critic: mg_int_forward + mg_ppo_loss + mg_int_backward in one call and,
+// with graph_slot >= 0, one updated graph launch (its ~58 launches are what bounds its update loop on the host)
+extern "C" int mg_int_ppo_step(const mg_int_cfg* c, const float* theta, const int32_t* mol_off, const int32_t* edge_off,
+                               const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* ws,
+                               size_t ws_bytes, const double* old_logp, const double* adv, const double* ret, double clip_ratio,
+                               double vf_coef, double entropy_coef, double loss_scale, float* out, float* gout, double* stats,
+                               double* stats_accum, float* grad_theta, int32_t graph_slot, int32_t* used_graph, void* stream) {
+  if (!c || !out || !gout || !stats || !grad_theta) MG_FAIL(MG_EINVAL, "mg_int_ppo_step: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  auto run = [&]() -> int {
+    int rc = mg_int_forward(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, out, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
+                       entropy_coef, stats, gout, loss_scale, stats_accum);
+    LAUNCH_CHECK();
+    return mg_int_backward(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, gout, grad_theta, stream);
+  };
+  if (used_graph) *used_graph = 0;
+  static int graphs_on = -1;
+  if (graphs_on < 0) { const char* e = getenv("MG_GRAPH"); graphs_on = e ? atoi(e) : 1; }
+  if (graph_slot >= 0 && graph_slot < MG_GRAPH_SLOTS && graphs_on && !g_prof_on && c->ME < MG_SIDE_MIN_EDGES) {
+    g_rec.begin(s);
+    int rc = run();
+    g_rec.end();
+    if (rc) return rc;
+    if (!g_rec.unsupported && !g_rec.recs.empty()) {
+      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][1][graph_slot], s);
+      if (e == hipSuccess) {
+        if (used_graph) *used_graph = 1;
+        return MG_OK;
+      }
+      (void)hipGetLastError();
     }
   }
   return run();

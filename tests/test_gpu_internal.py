@@ -79,6 +79,27 @@ def test_evaluate_actions_matches_oracle(built_lib):
         assert rel_err(out[k], exp[k]) < 1e-5, k
 
 
+def test_graph_step_equals_stream_launches(built_lib):
+    """mg_int_ppo_step as one updated hipGraph launch == the same ~58 launches issued to the stream (statistics and step outputs
+    bit for bit, gradient to the reproducibility of its float atomics), for mini-batches of different ragged sizes through the
+    same cached graph"""
+    ac, ref = _pair(6)
+    for k, B in enumerate((20, 33, 7)):
+        d = make_batch_internal(B, N, ZS, seed=10 + k)
+        batch = ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret'])
+        res = {}
+        for mode in (False, True):
+            ac.theta.grad = torch.zeros_like(ac.theta)
+            acc = torch.zeros(6, dtype=torch.float64, device='cuda')
+            stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=0.25, stats_accum=acc, graph=mode)
+            torch.cuda.synchronize()
+            assert ac.last_step_used_graph == mode
+            res[mode] = (stats.clone(), ac.theta.grad.clone(), acc.clone())
+        assert torch.equal(res[False][0], res[True][0])
+        assert torch.allclose(res[True][2], 0.25 * res[True][0], rtol=1e-14, atol=0)
+        assert (res[False][1] - res[True][1]).abs().max().item() <= 2e-5 * res[False][1].abs().max().item()
+
+
 def test_small_canvases_and_masks(built_lib):
     """n = 0, 1, 2 exercise the action masks (distance / angle / dihedral / kappa) and the null-atom focus."""
     ac, ref = _pair(3, width=64)

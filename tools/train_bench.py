@@ -30,7 +30,7 @@ else:
     d = make_batch(n, cfg['canvas_size'], cfg['zs'], seed=0)
 data = {'obs': d['obs'], 'act': d['act'], 'logp': d['logp'], 'adv': d['adv'], 'ret': d['ret']}
 opt = torch.optim.Adam(ac.parameters(), lr=1e-5)
-modes = [None] if name == 'internal' else [False, True, False, True]
+modes = [True, False, True, False] if name == 'internal' else [False, True, False, True]
 for rep, mode in enumerate(modes if len(sys.argv) <= 5 else [bool(int(sys.argv[5]))] * 3):
     if mode is not None:
         ac.use_graphs = mode  # ppo_minibatch as one updated hipGraph launch (True) or ~27 stream launches (False)
