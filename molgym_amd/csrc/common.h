@@ -30,11 +30,14 @@ static_assert(2 * NLM * CE <= 256, "num_channels_per_element <= 5: one 256-threa
 #ifdef MG_TS
 __device__ unsigned long long g_ts[128];
 __device__ int g_ts_block;
+__device__ unsigned long long g_wg_ts[3 * 256 * 4];  // heads: {forward start, forward end, backward start, backward end} of every workgroup
+#define WGTS(role, b, k) do { if (threadIdx.x == 0 && (b) < 256) g_wg_ts[(((role) * 256) + (b)) * 4 + (k)] = wall_clock64(); } while (0)
 #define TS(i) do { if (blockIdx.x == g_ts_block && blockIdx.y == 0 && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
 #define TSY(i) do { if (blockIdx.x == g_ts_block && threadIdx.x == 0) g_ts[i] = wall_clock64(); } while (0)
 #else
 #define TS(i) do { } while (0)
 #define TSY(i) do { } while (0)
+#define WGTS(role, b, k) do { } while (0)
 #endif
 
 // Workgroup barrier that waits for the wave's LDS traffic ONLY.  __syncthreads() is "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier":

@@ -730,4 +730,10 @@ extern "C" int mg_debug_ts(unsigned long long* out, int block) {
   HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_block), &block, sizeof(int)));
   return MG_OK;
 }
+// (tools/ts_heads_wg.sh) the start / end stamps of every workgroup of the two heads kernels
+extern "C" int mg_debug_wg_ts(unsigned long long* out) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_ts), sizeof(unsigned long long) * 3 * 256 * 4));
+  return MG_OK;
+}
 #endif
