@@ -38,7 +38,8 @@ extern "C" {
 #define MG_MAX_Z 8
 
 /* Fixed by the build (reference defaults, molgym/tools/arg_parser.py:55-60):
- * maxl = 4, num_cg_levels = 3, num_channels_hidden = 10, num_channels_per_element = 4. */
+ * maxl = 4, num_cg_levels = 3, num_channels_hidden = 10, num_channels_per_element = 4; the last three are -D parameters
+ * of other builds of the same sources (mg_cov_build_params). */
 typedef struct mg_cov_cfg {
   int32_t B;            /* samples in the mini-batch                                   */
   int32_t N;            /* canvas_size                                                 */
@@ -57,13 +58,17 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step.  */
-#define MG_ABI_VERSION 6
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step; 7: mg_cov_build_params (num_cg_levels a build parameter).  */
+#define MG_ABI_VERSION 7
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
  * Other values are other builds of the same sources (hipcc -DCH=.. -DCE=..); molgym_amd/_lib.py builds / loads them.   */
 int mg_cov_channels(int32_t* hidden, int32_t* per_element);
+/* the same, with maxl and num_cg_levels (arg_parser.py:55-56).  num_cg_levels is a build parameter too (hipcc -DNLEV=2..4:
+ * the level loops, arena and parameter layout follow it; the one-launch-per-level kernels of the small mini-batches are
+ * written for 3 and fall back to the general launches otherwise); maxl = 4 is fixed (tables, thread maps, LDS layouts).   */
+int mg_cov_build_params(int32_t* hidden, int32_t* per_element, int32_t* maxl, int32_t* num_cg_levels);
 
 /* ---- optional kernel-span timing (measurement only) ------------------------------ */
 /* on != 0: forward/backward bracket their dominant kernels with HIP events recorded on

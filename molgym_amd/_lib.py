@@ -33,6 +33,7 @@ SYMBOLS = {
     'mg_last_error': (C.c_char_p, []),
     'mg_abi_version': (C.c_int, []),
     'mg_cov_channels': (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'mg_cov_build_params': (C.c_int, [C.POINTER(C.c_int32)] * 4),
     'mg_profile_enable': (C.c_int, [C.c_int]),
     'mg_profile_report': (C.c_int, [C.c_char_p, C.c_size_t]),
     'mg_cov_num_params': (C.c_int, [C.POINTER(CovCfg), C.POINTER(C.c_int64)]),
@@ -75,9 +76,17 @@ SYMBOLS = {
 _lib = None
 _variants = {}
 DEFAULT_CHANNELS = (10, 4)  # num_channels_hidden, num_channels_per_element of the default build (arg_parser.py:55-60)
+DEFAULT_LEVELS = 3  # num_cg_levels of the default build (arg_parser.py:56); 2 .. 4 are other builds of the same sources
+LEVELS_RANGE = (2, 4)
 
 
-ABI_VERSION = 6  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+def _build_key(channels):
+    """(num_channels_hidden, num_channels_per_element[, num_cg_levels]) -> the full key of a library build"""
+    key = tuple(int(c) for c in channels)
+    return key if len(key) == 3 else key + (DEFAULT_LEVELS, )
+
+
+ABI_VERSION = 7  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
 
 
 def _bind(path):
@@ -100,8 +109,10 @@ def _bind(path):
 
 
 def variant_path(channels):
-    ch, ce = channels
-    return LIB_PATH if tuple(channels) == DEFAULT_CHANNELS else os.path.join(_HERE, f'libmolgym_hip_c{ch}e{ce}.so')
+    ch, ce, nlev = _build_key(channels)
+    if (ch, ce, nlev) == DEFAULT_CHANNELS + (DEFAULT_LEVELS, ):
+        return LIB_PATH
+    return os.path.join(_HERE, f'libmolgym_hip_c{ch}e{ce}' + ('' if nlev == DEFAULT_LEVELS else f'n{nlev}') + '.so')
 
 
 def _sources_mtime():
@@ -110,13 +121,14 @@ def _sources_mtime():
 
 
 def build_variant(channels, force=False):
-    """hipcc build of the same sources for other channel counts (compile-time constants of the kernels): in-tree, next to
-    the default library.  Needs hipcc (present in the ROCm image on both the build container and the GPU box).
+    """hipcc build of the same sources for other channel counts / another num_cg_levels (compile-time constants of the
+    kernels; `channels` = (C, Ce) or (C, Ce, num_cg_levels)): in-tree, next to the default library.  Needs hipcc (present in the ROCm image on both the build container and the GPU box).
     Several ranks of one torchrun launch may get here at once: the build is serialised by a file lock, goes to a temporary
     file in the same directory and is moved into place atomically, so nobody ever dlopens a half-written library."""
     import fcntl
     import subprocess
     import tempfile
+    channels = _build_key(channels)
     path = variant_path(channels)
     src = os.path.join(_HERE, 'csrc', 'molgym_hip.hip')
 
@@ -127,7 +139,7 @@ def build_variant(channels, force=False):
         return path
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
-        raise RuntimeError(f'num_channels_hidden={channels[0]}, num_channels_per_element={channels[1]} need their own build '
+        raise RuntimeError(f'num_channels_hidden={channels[0]}, num_channels_per_element={channels[1]}, num_cg_levels={channels[2]} need their own build '
                            f'of the library and {hipcc} is not there')
     try:
         lock = open(path + '.lock', 'w')
@@ -143,7 +155,7 @@ def build_variant(channels, force=False):
             os.close(fd)
             try:
                 subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-                                       f'-DCH={channels[0]}', f'-DCE={channels[1]}', src, '-o', tmp])
+                                       f'-DCH={channels[0]}', f'-DCE={channels[1]}', f'-DNLEV={channels[2]}', src, '-o', tmp])
                 os.chmod(tmp, 0o755)
                 os.replace(tmp, path)
             finally:
@@ -159,21 +171,24 @@ MAX_CHANNELS = (10, 5)  # csrc/common.h static_asserts: NLM * CH <= 256, 2 * NLM
 
 def lib(channels=None):
     """Load (once) and return the library; raises if it is not built.  `channels` = (num_channels_hidden,
-    num_channels_per_element) selects the build of the Cormorant kernels (None / (10, 4): the default library; anything else
-    is compiled on first use, see build_variant)."""
+    num_channels_per_element[, num_cg_levels]) selects the build of the Cormorant kernels (None / (10, 4) / (10, 4, 3): the
+    default library; anything else is compiled on first use, see build_variant)."""
     global _lib
-    if channels is not None and tuple(channels) != DEFAULT_CHANNELS:
-        key = tuple(int(c) for c in channels)
+    if channels is not None and _build_key(channels) != DEFAULT_CHANNELS + (DEFAULT_LEVELS, ):
+        key = _build_key(channels)
         if key not in _variants:
+            if not LEVELS_RANGE[0] <= key[2] <= LEVELS_RANGE[1]:
+                raise RuntimeError(f'num_cg_levels {key[2]} outside what the kernels were written for '
+                                   f'({LEVELS_RANGE[0]}..{LEVELS_RANGE[1]})')
             if key[0] < 1 or key[0] > MAX_CHANNELS[0] or key[1] < 1 or key[1] > MAX_CHANNELS[1]:
                 raise RuntimeError(f'num_channels_hidden {key[0]} / num_channels_per_element {key[1]} outside what the '
                                    f'kernels were written for (1..{MAX_CHANNELS[0]} / 1..{MAX_CHANNELS[1]}: one 256-thread '
                                    'workgroup covers the 25 * C items of an atom)')
             handle = _bind(build_variant(key))
-            ch, ce = C.c_int32(), C.c_int32()
-            handle.mg_cov_channels(C.byref(ch), C.byref(ce))
-            if (ch.value, ce.value) != key:
-                raise RuntimeError(f'{variant_path(key)} was built for channels {(ch.value, ce.value)}')
+            ch, ce, ml, nl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            handle.mg_cov_build_params(C.byref(ch), C.byref(ce), C.byref(ml), C.byref(nl))
+            if (ch.value, ce.value, nl.value) != key:
+                raise RuntimeError(f'{variant_path(key)} was built for channels / levels {(ch.value, ce.value, nl.value)}')
             _variants[key] = handle
         return _variants[key]
     if _lib is None:

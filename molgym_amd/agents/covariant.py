@@ -135,12 +135,15 @@ class CovariantAC(FlatThetaAgent):
         device=None,
     ):
         super().__init__(observation_space, action_space)
-        if (maxl, num_cg_levels) != (layout.MAXL, layout.NLEV):
-            raise RuntimeError('the gfx950 kernels are built for maxl=4, num_cg_levels=3 (the reference defaults, '
-                               'arg_parser.py:55-60; every BASELINE config uses them)')
-        # the channel counts are compile-time constants of a library build: the defaults load libmolgym_hip.so, other
-        # values their own build of the same sources (compiled on first use, molgym_amd/_lib.py::build_variant)
-        self._channels = (int(num_channels_hidden), int(num_channels_per_element))
+        if maxl != layout.MAXL:
+            raise RuntimeError('the gfx950 kernels are built for maxl=4 (the reference default, arg_parser.py:55; every BASELINE '
+                               'config uses it): the Clebsch-Gordan tables, thread maps and LDS layouts are laid out for 25 (l, m) rows')
+        if not _lib.LEVELS_RANGE[0] <= int(num_cg_levels) <= _lib.LEVELS_RANGE[1]:
+            raise RuntimeError(f'num_cg_levels {num_cg_levels}: the kernels cover {_lib.LEVELS_RANGE[0]}..{_lib.LEVELS_RANGE[1]}')
+        # the channel counts and num_cg_levels are compile-time constants of a library build: the defaults load
+        # libmolgym_hip.so, other values their own build of the same sources (compiled on first use,
+        # molgym_amd/_lib.py::build_variant)
+        self._channels = (int(num_channels_hidden), int(num_channels_per_element), int(num_cg_levels))
         self.device = torch.device(device) if device is not None else torch.device('cuda')
         self.dtype = torch.float
         self.zs = list(self.observation_space.zs)
@@ -153,7 +156,7 @@ class CovariantAC(FlatThetaAgent):
             raise RuntimeError(f'network_width {network_width}: the HIP heads kernels support multiples of 4 up to 128')
         self.num_gaussians, self.network_width, self.bag_scale = num_gaussians, network_width, bag_scale
         self.num_channels_out = len(self.zs) * num_channels_per_element
-        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)
+        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)  # (C, Ce, levels)
         self._L()  # load (build) the library for these channel counts now: a missing toolchain fails here, not mid-rollout
         self.theta = torch.nn.Parameter(self._init_theta(total))
         self.register_buffer('leb', torch.from_numpy(lebedev_table()), persistent=False)

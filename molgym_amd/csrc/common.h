@@ -18,7 +18,11 @@
 // fused heads): a build with more channels would silently leave the tail unwritten, so it does not compile.
 static_assert(NLM * CH <= 256, "num_channels_hidden <= 10: one 256-thread workgroup covers the NLM * CH items of an atom");
 static_assert(2 * NLM * CE <= 256, "num_channels_per_element <= 5: one 256-thread workgroup covers the 2 * NLM * CE mixer outputs");
-#define NLEV 3   // num_cg_levels
+#ifndef NLEV
+#define NLEV 3   // num_cg_levels: a build parameter like CH / CE (arg_parser.py:56; 2 .. 4; molgym_amd/_lib.py builds the variants)
+#endif
+static_assert(NLEV >= 2 && NLEV <= 4, "num_cg_levels 2 .. 4");
+#define NLEVA (NLEV < 3 ? 3 : NLEV)  // extent of the per-level arrays: the fused small-batch kernels (NLEV == 3 only) name levels 1, 2
 #define NRADF 32 // radial features per level
 #define NLEB 1730
 #define LEB_STRIDE 51

@@ -103,6 +103,14 @@ extern "C" int mg_cov_channels(int32_t* hidden, int32_t* per_element) {
   return MG_OK;
 }
 
+extern "C" int mg_cov_build_params(int32_t* hidden, int32_t* per_element, int32_t* maxl, int32_t* num_cg_levels) {
+  if (hidden) *hidden = CH;
+  if (per_element) *per_element = CE;
+  if (maxl) *maxl = MAXL;
+  if (num_cg_levels) *num_cg_levels = NLEV;
+  return MG_OK;
+}
+
 extern "C" int mg_cov_num_params(const mg_cov_cfg* cfg, int64_t* num_params) {
   PLayout P;
   int rc = build_layout(cfg, &P);
@@ -167,7 +175,7 @@ struct ListsJob {  // the small list build riding on the weight-preparation laun
 };
 static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scratch = false, const ListsJob* lj = nullptr) {
   std::vector<Lin*> all;
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < NLEV; ++k)
     for (int l = 0; l < 5; ++l) { all.push_back(&w.rad[k][l]); all.push_back(&w.edge[k][l]); all.push_back(&w.atom[k][l]); }
   all.push_back(&w.lin_in);
   for (int l = 0; l < 5; ++l) all.push_back(&w.mix[l]);
@@ -289,7 +297,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     input_done = true;
   } else if (TE > 0) {
     GeomArgs ga = {TE, N, pos, theta, (int)P.rad_scales[0], (int)P.rad_phases[0], (int)(P.rad_scales[1] - P.rad_scales[0]),
-                   soft_rad, soft_width, {w.r, w.em, w.Y, {w.phi[0], w.phi[1], w.phi[2]}}};
+                   soft_rad, soft_width, {w.r, w.em, w.Y, {}}};
+    for (int k = 0; k < NLEV; ++k) ga.out.phi[k] = w.phi[k];
     const unsigned n_geom = (unsigned)((4 * TE + 255) / 256);
     if (!weights_ready && TA > 0 && !side_active()) {  // one stream: the input Linear rides on the geometry launch
       hipLaunchKernelGGL(k_geom_input, dim3(n_geom + n_in), dim3(256), 0, s, ga, ia, w.L, (int)n_geom);
@@ -304,17 +313,17 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     // and the first DotMatrix (they fill the radial columns of cat_e[k]; joined before the first edge cat-mix)
     hipStream_t ss = side_fork(s);
     if (!w.shared_dot) {
-      GemmG gr[15];  // one launch for the 3 x 5 radial Linears
-      for (int k = 0; k < 3; ++k)
+      GemmG gr[5 * NLEV];  // one launch for the NLEV x 5 radial Linears
+      for (int k = 0; k < NLEV; ++k)
         for (int l = 0; l < 5; ++l)
           gr[5 * k + l] = fwd_group(w.rad[k][l], theta, w.phi[k], NRADF, w.cat_e[k][l] + w.rcol[k][l], w.ld_e[k][l], TE,
                                     0, nullptr);
-      RC(launch_gemm(ss, gr, 15));
+      RC(launch_gemm(ss, gr, 5 * NLEV));
     } else {
     SxArgs ra;  // one launch for the 3 x 5 radial Linears: the five of a level share its radial basis
     memset(&ra, 0, sizeof(ra));
     ra.rows = TE;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NLEV; ++k) {
       SxSet& S = ra.set[k];
       S.Xs = w.phi[k]; S.ldxs = NRADF; S.Rs = NRADF; S.ngroups = 5;
       for (int l = 0; l < 5; ++l) {
@@ -325,7 +334,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
         g.Y = w.cat_e[k][l] + w.rcol[k][l]; g.ldy = w.ld_e[k][l];
       }
     }
-    RC(launch_sx(ss, ra, 3));
+    RC(launch_sx(ss, ra, NLEV));
     }
   }
   if (TA > 0 && !input_done) {
@@ -334,7 +343,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     hipLaunchKernelGGL(k_input_linear, dim3(n_in), dim3(256), 0, s, ia, w.L);
     LAUNCH_CHECK();
   }
-  for (int k = fused0 ? 1 : 0; k < 3 && TA > 0; ++k) {
+  for (int k = fused0 ? 1 : 0; k < NLEV && TA > 0; ++k) {
     // --- edge level k (cormorant EdgeLevel: DotMatrix, cat-mix, soft mask) ---
     const bool fusedE = k >= 1 && edge_level_fused(fused0, N);
     if (fusedE) {
@@ -342,12 +351,12 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       memset(&ea, 0, sizeof(ea));
       for (int l = 0; l < 5; ++l) {
         ea.A[l] = w.A[k][l]; ea.row[l] = w.cat_e[k][l];
-        ea.out[l] = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
+        ea.out[l] = (k < NLEV - 1) ? w.cat_e[k + 1][l] : w.Elast[l];
         ea.mb[l] = w.edge[k][l].mb;
         if (w.ld_e[k][l] != EL_K || w.edge[k][l].ldb != w.edge[k][0].ldb || w.edge[k][l].K != EL_K)
           MG_FAIL(MG_EINVAL, "edge-level kernel: unexpected row layout");
       }
-      ea.ld_row = EL_K; ea.ld_out = (k < 2) ? w.ld_e[k + 1][0] : 2 * CH; ea.ldb = w.edge[k][0].ldb;
+      ea.ld_row = EL_K; ea.ld_out = (k < NLEV - 1) ? w.ld_e[k + 1][0] : 2 * CH; ea.ldb = w.edge[k][0].ldb;
       ea.em = w.em; ea.Acm = w.Acm[k]; ea.TA = TA; ea.N = N;
       ProfScope prof(s, "k_edge_level");
       hipLaunchKernelGGL(k_edge_fwd, dim3(TA), dim3(EL_T), el_fwd_lds_bytes(N), s, ea, w.L);
@@ -378,8 +387,8 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
     } else if (k == 0 || !w.shared_dot) {
       GemmG ge[5];
       for (int l = 0; l < 5; ++l) {
-        float* Ek = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
-        const int ldE = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+        float* Ek = (k < NLEV - 1) ? w.cat_e[k + 1][l] : w.Elast[l];
+        const int ldE = (k < NLEV - 1) ? w.ld_e[k + 1][l] : 2 * CH;
         ge[l] = fwd_group(w.edge[k][l], theta, w.cat_e[k][l], w.ld_e[k][l], Ek, ldE, TE, 0, w.em);
       }
       RC(launch_gemm(s, ge, 5));  // (level 0: l = 0 has a different reduction width; the MFMA row form takes both)
@@ -400,16 +409,16 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
         g.row_p1 = 12 * CH; g.Rp1 = 2 * CH;
         g.Xp = w.cat_e[k][l]; g.ldxp = w.ld_e[k][l];
         g.bias = E.b_off >= 0 ? theta + E.b_off : nullptr;
-        g.Y = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
-        g.ldy = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+        g.Y = (k < NLEV - 1) ? w.cat_e[k + 1][l] : w.Elast[l];
+        g.ldy = (k < NLEV - 1) ? w.ld_e[k + 1][l] : 2 * CH;
       }
       RC(launch_sx(s, ea, 1));
     }
     // --- atom level k (CG aggregate, CG power, cat-mix) ---
     EPtrs E;
     for (int l = 0; l < 5; ++l) {
-      E.p[l] = (k < 2) ? w.cat_e[k + 1][l] : w.Elast[l];
-      E.ld[l] = (k < 2) ? w.ld_e[k + 1][l] : 2 * CH;
+      E.p[l] = (k < NLEV - 1) ? w.cat_e[k + 1][l] : w.Elast[l];
+      E.ld[l] = (k < NLEV - 1) ? w.ld_e[k + 1][l] : 2 * CH;
     }
     CatDst cd;
     for (int l = 0; l < 5; ++l) { cd.p[l] = w.cat_a[k][l]; cd.ld[l] = w.ld_a[k][l]; }
@@ -435,7 +444,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   stream_wait(s, weights_ready);  // only still pending for a batch of empty canvases
   const int Co = P.Co, nlat = P.nlat;
   APtrs A3;
-  for (int l = 0; l < 5; ++l) A3.p[l] = w.A[3][l];
+  for (int l = 0; l < 5; ++l) A3.p[l] = w.A[NLEV][l];
   A3.C = Co;
   if (!smp && !use_staged_heads()) {  // action evaluation: all heads in one launch (heads_fused.inc)
     HeadDims HD;

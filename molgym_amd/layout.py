@@ -27,10 +27,10 @@ def mix_tau(l: int, ce: int = CE) -> int:
     return ce * (NBLK[l] + 2)
 
 
-def slots(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE) -> 'OrderedDict[str, Tuple[int, ...]]':
+def slots(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE, nlev: int = NLEV) -> 'OrderedDict[str, Tuple[int, ...]]':
     """`ch` / `ce`: num_channels_hidden / num_channels_per_element (arg_parser.py:55-60); the library build has to match
-    (molgym_amd/_lib.py::lib(channels))"""
-    CH, CE = ch, ce  # noqa: N806 (shadow the defaults below)
+    (molgym_amd/_lib.py::lib(channels)); `nlev`: num_cg_levels (arg_parser.py:56), a build parameter of the library too"""
+    CH, CE, NLEV = ch, ce, nlev  # noqa: N806 (shadow the defaults below)
     co = num_zs * CE
     nlat, nlat_e = (MAXL + 2) * co * 2, (MAXL + 2) * CE * 2
     s: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
@@ -62,10 +62,10 @@ def slots(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = C
     return s
 
 
-def offsets(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE):
+def offsets(num_zs: int, width: int, num_gaussians: int, ch: int = CH, ce: int = CE, nlev: int = NLEV):
     """name -> (offset, shape); also returns the total length."""
     out, off = OrderedDict(), 0
-    for name, shape in slots(num_zs, width, num_gaussians, ch, ce).items():
+    for name, shape in slots(num_zs, width, num_gaussians, ch, ce, nlev).items():
         n = 1
         for d in shape:
             n *= d

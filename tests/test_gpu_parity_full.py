@@ -126,3 +126,53 @@ def test_other_channel_counts_vs_oracle(built_lib):
     for k in ('logp', 'ent', 'v'):
         assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
     assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
+
+
+@pytest.mark.parametrize('levels', [2, 4])
+def test_other_num_cg_levels_vs_oracle(built_lib, levels):
+    """num_cg_levels = 2 / 4 (arg_parser.py:56 makes it a command-line flag; 3 is the default): a build parameter of the
+    library like the channel counts (hipcc -DNLEV=..; __graft_entry__.build() pre-builds both) -- the level loops, the arena
+    and the parameter layout follow it.  Outputs and every parameter gradient against the oracle built with the same
+    num_cg_levels, the C-side parameter layout against molgym_amd/layout.py, and the PPO mini-batch call (forward, loss,
+    backward in one call / one graph launch) against the autograd path."""
+    import ctypes as C
+    from molgym_amd import _lib, layout
+    ac, ref, cfg = make_pair('cfg2', seed=27, num_cg_levels=levels)
+    lib = ac._L()
+    got = [C.c_int32() for _ in range(4)]
+    lib.mg_cov_build_params(*[C.byref(g) for g in got])
+    assert [g.value for g in got] == [10, 4, 4, levels] and lib is not _lib.lib()
+    ccfg = ac._make_cfg(1, np.array([1]))
+    n = C.c_int64()
+    _lib.check(lib.mg_cov_num_params(C.byref(ccfg), C.byref(n)), lib)
+    table, total = layout.offsets(len(cfg['zs']), 128, 3, 10, 4, levels)
+    assert n.value == total == ac.theta.numel() and sum(p.numel() for p in ref.parameters()) == total
+    assert f'cg_model.cormorant_cg.atom_levels.{levels - 1}.cat_mix.weights.0' in table
+    assert f'cg_model.cormorant_cg.atom_levels.{levels}.cat_mix.weights.0' not in table
+    data = make_batch(12, cfg['canvas_size'], cfg['zs'], seed=35)
+    B = len(data['obs'])
+    g = torch.Generator().manual_seed(3)
+    wl, we, wv = (torch.randn(B, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
+    out = ac.step(data['obs'], data['act'])
+    (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
+    assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
+    # the one-call mini-batch step of ppo.train on this build
+    g_auto = ac.theta.grad.detach().clone()
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01).clone()
+    torch.cuda.synchronize()
+    g_step = ac.theta.grad.detach().clone()
+    ac.theta.grad = None
+    from molgym_amd import ppo as ppo_mod
+    loss, info = ppo_mod.compute_loss(ac, data, 0.2, 0.5, 0.01)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (g_step - ac.theta.grad).abs().max().item() <= 2e-5 * max(1.0, g_step.abs().max().item())
+    assert abs(stats[3].item() - info['total_loss']) <= 1e-6 * max(1.0, abs(info['total_loss']))
+    assert torch.isfinite(stats).all() and g_auto.abs().max() > 0

@@ -83,6 +83,39 @@ def test_channel_counts_outside_the_kernels_range_are_refused():
             _lib.lib(bad)
 
 
+def test_num_cg_levels_is_a_build_parameter_with_its_own_library_and_layout(built_lib):
+    """num_cg_levels (arg_parser.py:56) selects a build of the library like the channel counts: its own file name, its own
+    parameter layout (molgym_amd/layout.py and the C side agree slot by slot); values outside 2..4 are refused before hipcc
+    starts.  __graft_entry__.build() pre-builds 2 and 4; the parity tests against the oracle are `-m gpu`."""
+    import os
+    from molgym_amd import _lib, layout
+    assert _lib.variant_path((10, 4)) == _lib.variant_path((10, 4, 3)) == _lib.LIB_PATH
+    assert _lib.variant_path((10, 4, 2)).endswith('libmolgym_hip_c10e4n2.so')
+    assert _lib.variant_path((8, 2)).endswith('libmolgym_hip_c8e2.so') and _lib.variant_path((8, 2, 4)).endswith('libmolgym_hip_c8e2n4.so')
+    for bad in ((10, 4, 1), (10, 4, 5), (10, 4, 0)):
+        with pytest.raises(RuntimeError):
+            _lib.lib(bad)
+    for levels in (2, 4):
+        if not os.path.exists(_lib.variant_path((10, 4, levels))):
+            pytest.skip('variant libraries not built (python -c "import __graft_entry__ as g; g.build()")')
+        lib = _lib.lib((10, 4, levels))
+        got = [C.c_int32() for _ in range(4)]
+        lib.mg_cov_build_params(*[C.byref(g) for g in got])
+        assert [g.value for g in got] == [10, 4, 4, levels]
+        cfg = _lib.CovCfg()
+        cfg.B, cfg.N, cfg.Z, cfg.W, cfg.G, cfg.TA, cfg.TE = 2, 7, 3, 128, 3, 3, 5
+        cfg.zs[0], cfg.zs[1], cfg.zs[2] = 0, 9, 16
+        cfg.min_distance, cfg.max_distance, cfg.bag_scale = 0.8, 1.8, 5
+        n = C.c_int64()
+        _lib.check(lib.mg_cov_num_params(C.byref(cfg), C.byref(n)), lib)
+        table, total = layout.offsets(3, 128, 3, 10, 4, levels)
+        assert n.value == total
+        offs = (C.c_int64 * 256)()
+        ns = C.c_int32()
+        _lib.check(lib.mg_cov_param_offsets(C.byref(cfg), offs, C.byref(ns)), lib)
+        assert ns.value == len(table) and [offs[i] for i in range(ns.value)] == [o for o, _ in table.values()]
+
+
 def test_invalid_configuration_is_reported(built_lib):
     from molgym_amd import _lib
     cfg = _lib.CovCfg()
