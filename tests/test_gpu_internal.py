@@ -12,17 +12,17 @@ pytestmark = pytest.mark.gpu
 ZS, N = [0, 9, 16], 7
 
 
-def _pair(seed, width=128):
+def _pair(seed, width=128, canvas=N):
     from molgym_amd.agents.internal import SchNetAC
     torch.manual_seed(seed)
-    ac = SchNetAC(ObservationSpace(N, ZS), ActionSpace(ZS), (0.8, 1.8), width, device='cuda:0')
+    ac = SchNetAC(ObservationSpace(canvas, ZS), ActionSpace(ZS), (0.8, 1.8), width, device='cuda:0')
     with torch.no_grad():
         g = torch.Generator().manual_seed(seed + 1)
         for name, (off, shape) in ac.slot_table.items():
             n = int(np.prod(shape))
             if name.endswith('bias'):
                 ac.theta[off:off + n] = (0.1 * torch.randn(n, generator=g)).to(ac.theta)
-    ref = SchNetACRef(ZS, N, (0.8, 1.8), width).double()
+    ref = SchNetACRef(ZS, canvas, (0.8, 1.8), width).double()
     ref.load_state_dict({k: v.double().cpu() for k, v in ac.export_state_dict().items()}, strict=True)
     return ac, ref
 
@@ -42,9 +42,12 @@ def test_vectorised_zmat_matches_scalar_helper(built_lib):
         np.testing.assert_allclose(got[b], want, rtol=1e-12, atol=1e-12)
 
 
-def test_outputs_and_gradients_match_oracle(built_lib):
-    ac, ref = _pair(0)
-    data = make_batch_internal(24, N, ZS, seed=4)
+@pytest.mark.parametrize('canvas,width', [(7, 128), (12, 128), (20, 128), (7, 64)])
+def test_outputs_and_gradients_match_oracle(built_lib, canvas, width):
+    """(7, 128) and (12, 128): the SchNet interactions as one launch per direction, 8- and 16-atom layouts (schnet_fused.inc);
+    (20, 128) and (7, 64): the per-layer launches (molecules above 16 atoms; atom features other than 64)"""
+    ac, ref = _pair(0, width, canvas)
+    data = make_batch_internal(24, canvas, ZS, seed=4)
     g = torch.Generator().manual_seed(1)
     wl, we, wv = (torch.randn(24, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
     out = ac.step(data['obs'], data['act'])
