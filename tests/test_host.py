@@ -169,3 +169,30 @@ def test_internal_batched_action_conversion_equals_per_sample():
     want = [ia.to_action_space(a, o) for a, o in zip(acts, data['obs'])]
     for g, w in zip(got, want):
         assert g[0] == w[0] and np.array_equal(np.asarray(g[1]), np.asarray(w[1]), equal_nan=True)
+
+
+def test_native_observation_parser_equals_the_numpy_path():
+    """molgym_amd/csrc/obsparse.c (one C traversal of the observation tuples, built by __graft_entry__.build()) fills the same
+    three arrays as the list comprehensions + np.array of ParsedObservations.from_list -- tuples, lists and numpy scalars alike --
+    and irregular input still ends in the numpy path's RuntimeError."""
+    from molgym_amd import observations as om
+    native = om._native_parser()
+    if native is None:
+        pytest.skip('molgym_amd/_obsparse.so not built (python -c "import __graft_entry__ as g; g.build()")')
+    cfg = CONFIGS['cfg2']
+    data = make_batch(37, cfg['canvas_size'], cfg['zs'], seed=5)
+    obs = list(data['obs'])
+    obs[3] = ([[np.int64(l), [np.float64(c) for c in p]] for l, p in obs[3][0]], list(obs[3][1]))  # lists + numpy scalars
+    got = om.ParsedObservations.from_list(obs)
+    labels = np.array([[item[0] for item in o[0]] for o in obs], dtype=np.int64)
+    xyz = np.array([[item[1] for item in o[0]] for o in obs], dtype=np.float64)
+    bags = np.array([o[1] for o in obs], dtype=np.int64)
+    assert np.array_equal(got.labels, labels) and np.array_equal(got.xyz, xyz) and np.array_equal(got.bags, bags)
+    saved, om._NATIVE = om._NATIVE, None  # the numpy path on the same input
+    try:
+        ref = om.ParsedObservations.from_list(obs)
+    finally:
+        om._NATIVE = saved
+    assert np.array_equal(ref.labels, got.labels) and np.array_equal(ref.xyz, got.xyz) and np.array_equal(ref.bags, got.bags)
+    with pytest.raises(RuntimeError):
+        om.ParsedObservations.from_list([obs[0], (obs[1][0][:3], obs[1][1])])
