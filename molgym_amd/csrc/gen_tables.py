@@ -102,10 +102,12 @@ def blocks(l):
 
 
 def main():
-    # (the bank-conflict search below takes ~20 s: skipped when the generated file is newer than this script)
+    # (the bank-conflict search below takes ~20 s: skipped when the generated file carries the hash of this version of the script)
+    import hashlib
     here = os.path.dirname(os.path.abspath(__file__))
     out_path = os.path.join(here, 'cg_tables.inc')
-    if '--force' not in sys.argv and os.path.exists(out_path) and os.path.getmtime(out_path) >= os.path.getmtime(os.path.abspath(__file__)):
+    gen_hash = hashlib.sha1(open(os.path.abspath(__file__), 'rb').read()).hexdigest()
+    if '--force' not in sys.argv and os.path.exists(out_path) and ('generator sha1: ' + gen_hash) in open(out_path).readline():
         return
     nblk = [len(blocks(l)) for l in range(MAXL + 1)]
     row_base, rb = [], 0
@@ -291,7 +293,7 @@ def main():
 
     out = []
     w = out.append
-    w('// GENERATED by gen_tables.py -- do not edit.  Sparse real Clebsch-Gordan tables, maxl = 4.')
+    w('// GENERATED by gen_tables.py (generator sha1: ' + gen_hash + ') -- do not edit.  Sparse real Clebsch-Gordan tables, maxl = 4.')
     w(f'#define CG_NNZ {len(terms)}')
     w(f'#define CG_NROWS {nrows}')
     w('static const int h_cg_nblk[5] = {' + ', '.join(map(str, nblk)) + '};')
@@ -337,8 +339,7 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'cg_tables.inc')
     text = '\n'.join(out) + '\n'
     if os.path.exists(path) and open(path).read() == text:
-        os.utime(path)  # unchanged: only mark it as checked against this version of the script (see the top of main)
-        return
+        return  # unchanged: keep the mtime so the library is not rebuilt
     with open(path, 'w') as fh:
         fh.write(text)
     print(f'wrote {path}: nnz={len(terms)} rows={nrows} nblk={nblk}', file=sys.stderr)
