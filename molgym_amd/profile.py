@@ -176,42 +176,59 @@ def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
 
 
 def internal_roofline(ac, batch):
-    """`roofline` object of the SchNet internal-coordinate agent (BASELINE configs[0]).  Its step is ~58 launches of small
-    dense products (0.49 ms at 140 samples); the dominant span is one of two families -- `k_gemm_rows` (every forward product and input adjoint)
-    or `k_gemm_dw` (every weight gradient, two bucketed launches).  achieved = the family's algorithmic flops -- 2 rows in out
-    per Linear layer and direction -- over its live HIP-event time per step, against the f32 MFMA peak; the fraction is tiny
-    because these are latency-bound launches of a few hundred workgroups, which is what the object is there to show."""
+    """`roofline` object of the SchNet internal-coordinate agent (BASELINE configs[0]).  Its step is a chain of ~35 short launches
+    (0.355 ms at 140 samples): the fused SchNet interactions (`k_schnet`), the fused filter networks (`k_filter`), the head MLPs
+    as grouped row / column GEMM launches (`k_gemm_rows`) and the bucketed weight gradients (`k_gemm_dw`).  Every family gets its
+    algorithmic flops -- 2 rows in out per Linear layer and direction it computes -- over its live HIP-event time per step
+    against the f32 MFMA peak (`families`); the headline entries are those of the family with the longest span.  The fractions are
+    small because these are latency-bound launches of a few hundred workgroups, which is what the object is there to show."""
     cfg = batch.cfg
     spans = kernel_spans(ac, batch)
     per_step = {k: v[0] * v[1] for k, v in spans.items()}
     if not per_step:
         return None
-    name = max(per_step, key=lambda k: per_step[k])
     B, TA, MA, ME, W, Z = cfg.B, cfg.TA, cfg.MA, cfg.ME, cfg.W, cfg.Z
     AF, LB, F, G = W // 2, W // 4, 128, 25
     NL = AF + LB
-    layers = 3 * [(ME, G, F), (ME, F, F), (MA, AF, F), (MA, F, AF), (MA, AF, AF)]          # SchNet interactions
-    layers += [(B, Z, W), (B, W, LB)] * 2                                                     # phi_beta, both uses
-    layers += [(TA, NL, W), (TA, W, 1), (B, NL, W), (B, W, Z), (B, NL + Z, W), (B, W, 3)]     # focus, element, continuous
-    layers += [(2 * B, NL, W), (2 * B, W, 1), (B, NL, W), (B, W, W), (B, W, 1)]               # kappa, critic
-    dw_flops = sum(2 * r * i * o for r, i, o in layers)
-    dw_bytes = sum(4 * (r * i + r * o + i * o) for r, i, o in layers)
+    filt = 3 * [(ME, G, F), (ME, F, F)]                                                      # filter-generating networks
+    atom = 3 * [(MA, AF, F), (MA, F, AF), (MA, AF, AF)]                                      # in2f, f2out, dense
+    heads = [(B, Z, W), (B, W, LB)] * 2                                                      # phi_beta, both uses
+    heads += [(TA, NL, W), (TA, W, 1), (B, NL, W), (B, W, Z), (B, NL + Z, W), (B, W, 3)]     # focus, element, continuous
+    heads += [(2 * B, NL, W), (2 * B, W, 1), (B, NL, W), (B, W, W), (B, W, 1)]               # kappa, critic
+    mm = lambda ls: sum(2 * r * i * o for r, i, o in ls)  # noqa: E731
+    nbytes = lambda ls: sum(4 * (r * i + r * o + i * o) for r, i, o in ls)  # noqa: E731
+    no_dx = {(ME, G, F), (B, Z, W)}  # inputs without a gradient: the Gaussian expansion of the distances, the bag vectors
+    fwd_dx = lambda ls: mm(ls) + mm([l for l in ls if l not in no_dx])  # noqa: E731
+    cfconv = 3 * (2 * ME * F + 4 * ME * F)  # agg = sum y * Wf; its two adjoints
+    fam_flops = {'k_gemm_dw': mm(filt + atom + heads)}
+    fam_bytes = {'k_gemm_dw': nbytes(filt + atom + heads)}
+    rows = list(heads)
+    if 'k_filter' in per_step:
+        fam_flops['k_filter'], fam_bytes['k_filter'] = fwd_dx(filt), 2 * nbytes(filt)
+    else:
+        rows += filt
+    if 'k_schnet' in per_step:
+        fam_flops['k_schnet'], fam_bytes['k_schnet'] = fwd_dx(atom) + cfconv, 2 * nbytes(atom) + 3 * 3 * 4 * ME * F
+    else:
+        rows += atom
+    fam_flops['k_gemm_rows'], fam_bytes['k_gemm_rows'] = fwd_dx(rows), 2 * nbytes(rows)
+    families = {}
+    for k, ms in per_step.items():
+        if k in fam_flops and ms > 0:
+            tf = fam_flops[k] / (ms * 1e-3) / 1e12
+            families[k] = {'us_per_step': ms * 1e3, 'flops_per_step': fam_flops[k], 'achieved_tflops': tf,
+                           'frac_f32_peak': tf / PEAK_F32_TFLOPS}
+    name = max(families, key=lambda k: families[k]['us_per_step']) if families else max(per_step, key=lambda k: per_step[k])
     sec = per_step[name] * 1e-3
     out = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_TFLOPS, 'kernel': name, 'kernel_ms_per_step': per_step[name],
-           'launches_per_step': spans[name][1], 'traffic': None, 'span_ms_per_step': per_step,
-           'note': 'SchNetAC: every dense product on v_mfma_f32_16x16x4_f32; the step is a chain of ~58 short launches, the '
-                   'longest span is the bucketed weight-gradient launches; achieved = algorithmic dW flops (2 rows in out '
-                   'per layer) / live HIP-event time of that span'}
-    # the forward products and the adjoints w.r.t. their inputs (`k_gemm_rows`: every launch of the row / column GEMM
-    # families): the same layers once forward, once more for every input that carries a gradient (not the Gaussian
-    # expansion of the distances, not the bag vectors)
-    no_dx = {(ME, G, F), (B, Z, W)}
-    rows_flops = dw_flops + sum(2 * r * i * o for r, i, o in layers if (r, i, o) not in no_dx)
-    flops = {'k_gemm_dw': dw_flops, 'k_gemm_rows': rows_flops}.get(name)
-    if flops is not None:
+           'launches_per_step': spans[name][1], 'traffic': None, 'span_ms_per_step': per_step, 'families': families,
+           'note': 'SchNetAC: every dense product on v_mfma_f32_16x16x4_f32 (f32 MFMA peak == the f32 vector peak on gfx950); the step '
+                   'is a chain of ~35 short launches; achieved / frac are those of the family with the longest span: its algorithmic '
+                   'flops (2 rows in out per layer and direction it computes) / its live HIP-event time per step'}
+    if name in fam_flops:
+        flops = fam_flops[name]
         out.update(achieved=flops / sec / 1e12, frac=flops / sec / 1e12 / PEAK_F32_TFLOPS, algorithmic_flops_per_step=flops,
-                   algorithmic_bytes_per_step=dw_bytes * (1 if name == 'k_gemm_dw' else 2),
-                   algorithmic_gbps=dw_bytes * (1 if name == 'k_gemm_dw' else 2) / sec / 1e9)
+                   algorithmic_bytes_per_step=fam_bytes[name], algorithmic_gbps=fam_bytes[name] / sec / 1e9)
     else:
         out.update(achieved=None, frac=None)
     return out
