@@ -117,7 +117,11 @@ def variant_path(channels):
 
 def _sources_mtime():
     d = os.path.join(_HERE, 'csrc')
-    return max(os.path.getmtime(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(('.hip', '.inc', '.h')))
+    srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith(('.hip', '.inc', '.h'))]
+    header = os.path.join(os.path.dirname(_HERE), 'include', 'molgym_hip.h')  # MG_ABI_VERSION lives there
+    if os.path.exists(header):
+        srcs.append(header)
+    return max(os.path.getmtime(f) for f in srcs)
 
 
 def build_variant(channels, force=False):

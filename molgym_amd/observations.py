@@ -19,13 +19,13 @@ _NATIVE = False
 
 
 def _native_parser():
-    """the C traversal (built by __graft_entry__.build() next to the package: molgym_amd/_obsparse.so), or None"""
+    """the C traversal (built by __graft_entry__.build() next to the package: molgym_amd/_obsparse<EXT_SUFFIX>), or None"""
     global _NATIVE
     if _NATIVE is False:
         try:
             from molgym_amd import _obsparse
             _NATIVE = _obsparse
-        except ImportError:
+        except Exception:  # not built, or built for another interpreter: the numpy path serves
             _NATIVE = None
     return _NATIVE
 

@@ -233,12 +233,40 @@ def _comm_device(dist) -> torch.device:
     return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
-def _epoch_batches(num_samples: int, mini_batch_size: int, dist, rank: int) -> List[np.ndarray]:
+class _SharedPermutations:
+    """The epoch permutations of one `train` call under torch.distributed, WITHOUT a collective (and its device -> host
+    synchronisation) per epoch.  The reference draws every epoch's permutation from the global numpy RNG (ppo.py:66-74) and
+    the ranks' global streams differ (the rollout moved them apart), so the ranks must agree on rank 0's permutations.  Nothing
+    else draws from that stream while `train` runs: ONE exchange of rank 0's generator state at the top of `train` lets every
+    rank replay rank 0's draws from a private clone (the run-ahead loop has three mini-batches in flight -- a broadcast + `.cpu()`
+    per epoch drained them at world > 1 only, on the path no single-GPU run covers).  Every rank still advances its own global
+    stream by the same draws, as before."""
+
+    def __init__(self, dist):
+        name, keys, pos, has_gauss, cached = np.random.get_state()
+        assert name == 'MT19937'
+        packed = np.concatenate([keys.astype(np.int64), [pos, has_gauss], np.frombuffer(np.float64(cached).tobytes(), dtype=np.int64)])
+        state = torch.from_numpy(packed).to(_comm_device(dist))
+        dist.broadcast(state, src=0)
+        got = state.cpu().numpy()
+        self.rng = np.random.RandomState()
+        self.rng.set_state(('MT19937', got[:624].astype(np.uint32), int(got[624]), int(got[625]),
+                            float(np.frombuffer(got[626:627].tobytes(), dtype=np.float64)[0])))
+
+    def get_state(self):
+        return self.rng.get_state()
+
+    def set_state(self, st):
+        self.rng.set_state(st)
+
+
+def _epoch_batches(num_samples: int, mini_batch_size: int, dist, rank: int, shared: Optional[_SharedPermutations] = None) -> List[np.ndarray]:
     batches = list(get_batch_generator(np.arange(num_samples), mini_batch_size))  # every rank advances its numpy RNG
     if dist is not None and num_samples > 0:  # ... but rank 0's permutation is the one everybody uses
-        perm = torch.from_numpy(np.concatenate(batches).astype(np.int64)).to(_comm_device(dist))
-        dist.broadcast(perm, src=0)
-        flat, sizes = perm.cpu().numpy(), [len(b) for b in batches]  # (the batch sizes follow from the two counts alone)
+        assert shared is not None
+        flat, sizes = shared.rng.permutation(np.arange(num_samples)), [len(b) for b in batches]  # (rank 0's draw, replayed)
+        if rank == 0:
+            assert np.array_equal(flat[:len(batches[0])], batches[0])
         batches = [flat[lo:lo + n] for lo, n in zip(np.concatenate([[0], np.cumsum(sizes)[:-1]]), sizes)]
     return batches
 
@@ -268,9 +296,13 @@ def _train_runahead(ac, optimizer, runner, num_samples: int, mini_batch_size: in
     is taken back, the numpy RNG is put back to where the reference's loop would have left it)."""
     dist, rank, world = _dist()
     dev = runner.dev
+    on_gpu = dev.type == 'cuda'
+    shared = _SharedPermutations(dist) if dist is not None else None
     stop = torch.zeros(1, dtype=torch.int32, device=dev)
     recs_dev = torch.zeros(max_num_steps, 8, dtype=torch.float64, device=dev)
-    recs_host = torch.zeros(max_num_steps, 8, dtype=torch.float64).pin_memory()
+    recs_host = torch.zeros(max_num_steps, 8, dtype=torch.float64)
+    if on_gpu:
+        recs_host = recs_host.pin_memory()
     events, rng_states, keep = [], [], []
     flags, issued = None, 0
     for p in ac.parameters():
@@ -280,7 +312,7 @@ def _train_runahead(ac, optimizer, runner, num_samples: int, mini_batch_size: in
         rng_states.append(np.random.get_state())
         for p in ac.parameters():
             p.grad.zero_()  # (optimizer.zero_grad(), in place: the launches of the epoch in flight hold the tensor's address)
-        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank)
+        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank, shared)
         slices = shard_epoch(batches, rank, world)
         runner.set_epoch([sl for sl, _ in slices])
         runner.begin_epoch()
@@ -298,18 +330,23 @@ def _train_runahead(ac, optimizer, runner, num_samples: int, mini_batch_size: in
         recs_host[i].copy_(recs_dev[i], non_blocking=True)
         if i == 0 and hasattr(ac, 'input_flags_async'):
             flags = ac.input_flags_async()  # inconsistent inputs raise at the first look below instead of training on garbage
-        ev = torch.cuda.Event()
-        ev.record()
+        # the event goes on the AGENT's stream (the one the record's copy was issued on): with an agent on cuda:1 while cuda:0 is
+        # current, a bare `record()` lands on cuda:0's stream and `synchronize()` returns before the copy has
+        ev = torch.cuda.Event() if on_gpu else None
+        if on_gpu:
+            with torch.cuda.device(dev):
+                ev.record(torch.cuda.current_stream(dev))
         events.append(ev)
         issued += 1
         if i >= 1:  # epoch i is queued: now look at epoch i - 1
-            events[i - 1].synchronize()
+            if on_gpu:
+                events[i - 1].synchronize()
             if flags is not None:
                 ac.raise_input_flags(flags)
                 flags = None
             if recs_host[i - 1, 7].item() != 0.0:
                 break
-    if events:
+    if events and on_gpu:
         events[-1].synchronize()
     if flags is not None:
         ac.raise_input_flags(flags)
@@ -337,7 +374,9 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
     device_path = hasattr(ac, 'prepare_rollout') and hasattr(ac, 'ppo_minibatch')
     runner = _DeviceRunner(ac, data, mini_batch_size, hp) if device_path else \
         _AutogradRunner(ac, data, mini_batch_size, hp, device)
-    flat = hasattr(ac, 'grad_norm_clip') and next(ac.parameters()).device.type == 'cuda'
+    # (`flat_gradient_on_host`: a stand-in agent that implements the flat-gradient calls in torch on the CPU -- tests/test_dp_gloo.py)
+    flat = hasattr(ac, 'grad_norm_clip') and (next(ac.parameters()).device.type == 'cuda' or
+                                               getattr(ac, 'flat_gradient_on_host', False))
     num_samples = len(data['obs'])
     num_epochs = 0
     import os
@@ -352,9 +391,10 @@ def train(ac, optimizer, data: Dict[str, Sequence], mini_batch_size: int, clip_r
         num_epochs = _train_runahead(ac, optimizer, runner, num_samples, mini_batch_size, target_kl, gradient_clip,
                                      max_num_steps, infos)
         max_num_steps = 0  # (the synchronous loop below is skipped)
+    shared = _SharedPermutations(dist) if dist is not None and max_num_steps > 0 else None
     for i in range(max_num_steps):
         optimizer.zero_grad()
-        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank)
+        batches = _epoch_batches(num_samples, mini_batch_size, dist, rank, shared)
         slices = shard_epoch(batches, rank, world)  # (this rank's sample indices, their share of the mini-batch)
         runner.set_epoch([sl for sl, _ in slices])
         runner.begin_epoch()

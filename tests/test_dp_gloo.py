@@ -62,6 +62,96 @@ class TinyDeviceAC(TinyAC):
         return torch.tensor([info[k] for k in ppo.KEYS], dtype=torch.float64)
 
 
+class TinyRunaheadAC(TinyDeviceAC):
+    """everything `ppo._train_runahead` calls on the HIP agents (FlatThetaAgent: statistics accumulated on the device, the
+    epoch's KL test / norm / clip as `ppo_epoch_end` with a latching stop flag, the Adam step gated by that flag and taken
+    back by `adam_unstep`), in plain torch on the CPU: what is under test is the loop around them"""
+    flat_gradient_on_host = True
+
+    def ppo_minibatch(self, batch, clip_ratio, vf_coef, entropy_coef, loss_scale=1.0, slot=0, stats_accum=None):
+        stats = super().ppo_minibatch(batch, clip_ratio, vf_coef, entropy_coef, loss_scale, slot)
+        stats_accum += stats * loss_scale
+        return None
+
+    def _grads(self):
+        return [p.grad for p in self.parameters()]
+
+    def grad_norm_clip(self, max_norm=0.0):
+        norm = torch.norm(torch.stack([torch.norm(g, 2) for g in self._grads()]), 2)
+        if max_norm > 0:
+            coef = max_norm / (norm + 1e-6)
+            if coef < 1:
+                for g in self._grads():
+                    g.mul_(coef)
+        return norm.reshape(1)
+
+    def ppo_epoch_end(self, max_norm, stats_accum, num_minibatches, kl_limit, rec, stop_flag):
+        stats = stats_accum / max(int(num_minibatches), 1)
+        stop = bool(stop_flag.item()) or stats[4].item() > kl_limit
+        norm = self.grad_norm_clip(0.0 if stop else max_norm)
+        rec[:6] = stats
+        rec[6] = norm.double()
+        rec[7] = 1.0 if stop else 0.0
+        if stop:
+            stop_flag.fill_(1)
+
+    def adam_supported(self, optimizer):
+        return True
+
+    def adam_step(self, optimizer, skip_flag=None):
+        self.steps_issued = getattr(self, 'steps_issued', 0) + 1
+        if skip_flag is None or skip_flag.item() == 0:
+            optimizer.step()
+            self.steps_taken = getattr(self, 'steps_taken', 0) + 1
+        return True
+
+    def adam_unstep(self, optimizer, count):
+        self.unstepped = getattr(self, 'unstepped', 0) + count
+
+
+def _kl_limited_data(n):
+    d = _data(n)
+    d['logp'] = d['logp'] + 0.05  # approx_kl = mean(old - new) starts at 0.06 and grows with the updates
+    return d
+
+
+def _run_runahead(rank, world, port, out, runahead):
+    os.environ['MOLGYM_RUNAHEAD'] = '1' if runahead else '0'
+    _init(rank, world, port)
+    ac = TinyRunaheadAC()
+    opt = torch.optim.Adam(ac.parameters(), lr=3e-2)
+    np.random.seed(11 + 100 * rank)
+    infos = ppo.train(ac, opt, _kl_limited_data(32), mini_batch_size=8, clip_ratio=0.2, target_kl=0.046, vf_coef=0.5,
+                      entropy_coef=0.01, gradient_clip=0.5, max_num_steps=6)
+    if rank == 0:
+        torch.save({'sd': ac.state_dict(), 'infos': {k: v for k, v in infos.items() if k != 'time'},
+                    'rng': np.random.get_state()[1], 'rng_pos': np.random.get_state()[2],
+                    'issued': getattr(ac, 'steps_issued', 0), 'taken': getattr(ac, 'steps_taken', 0),
+                    'unstepped': getattr(ac, 'unstepped', 0)}, out)
+    _done(world)
+
+
+def test_runahead_loop_with_early_kl_stop_world2_equals_the_synchronous_loop(tmp_path):
+    """`_train_runahead` (the epochs without a host round trip: KL test on the device, gated Adam, epoch i + 1 issued before epoch
+    i's record is read) at world 2 over gloo against the reference-shaped synchronous loop in one process: same theta, same
+    statistics, same number of optimizer steps, and the numpy RNG left where the synchronous loop leaves it (the speculative
+    epoch's permutation is taken back)."""
+    sync, ahead = str(tmp_path / 'sync.pt'), str(tmp_path / 'ahead.pt')
+    _run_runahead(0, 1, 0, sync, False)
+    mp.spawn(_run_runahead, args=(2, _free_port(), ahead, True), nprocs=2, join=True)
+    os.environ.pop('MOLGYM_RUNAHEAD', None)
+    a, b = torch.load(sync, weights_only=False), torch.load(ahead, weights_only=False)
+    assert 1 <= a['infos']['num_opt_steps'] < 5, a['infos']  # the KL limit stops the loop early, after at least one update
+    assert b['infos']['num_opt_steps'] == a['infos']['num_opt_steps']
+    assert b['taken'] == a['infos']['num_opt_steps'] and b['issued'] - b['unstepped'] == b['taken']
+    assert b['issued'] > b['taken']  # the run-ahead loop did issue an epoch behind the one that stopped
+    for k in a['sd']:
+        assert torch.allclose(a['sd'][k], b['sd'][k], atol=1e-6, rtol=1e-5), k
+    for k in a['infos']:
+        assert abs(a['infos'][k] - b['infos'][k]) < 1e-6 * max(1.0, abs(a['infos'][k])), k
+    assert b['rng_pos'] == a['rng_pos'] and np.array_equal(a['rng'], b['rng'])
+
+
 def _data(n):
     d = make_batch(n, 7, [0, 9, 16], seed=3)
     ac = TinyAC()

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: observation parsing, parameter layout, the C ABI surface."""
 import ctypes as C
+import os
 import re
 
 import numpy as np
@@ -196,3 +197,59 @@ def test_native_observation_parser_equals_the_numpy_path():
     assert np.array_equal(ref.labels, got.labels) and np.array_equal(ref.xyz, got.xyz) and np.array_equal(ref.bags, got.bags)
     with pytest.raises(RuntimeError):
         om.ParsedObservations.from_list([obs[0], (obs[1][0][:3], obs[1][1])])
+
+
+def test_native_observation_parser_under_address_sanitizer(tmp_path):
+    """SURVEY section 5's sanitizer pass for the one piece of native HOST code on the path: csrc/obsparse.c rebuilt with
+    -fsanitize=address,undefined and driven in a child interpreter (libasan preloaded) over regular rollouts, tuples / lists /
+    numpy scalars, empty input and the irregular inputs that must end in an exception -- any out-of-bounds access, use after
+    free or reference-count slip on those paths aborts the child."""
+    import shutil
+    import subprocess
+    import sys
+    import sysconfig
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    libasan = subprocess.run([gcc, '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip('no libasan')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = tmp_path / 'asanpkg'
+    pkg.mkdir()
+    ext = pkg / ('_obsparse' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+    subprocess.check_call([gcc, '-O1', '-g', '-fno-omit-frame-pointer', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                           '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include'],
+                           os.path.join(root, 'molgym_amd', 'csrc', 'obsparse.c'), '-o', str(ext)])
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import _obsparse
+assert _obsparse.__file__.startswith(sys.argv[2]), _obsparse.__file__
+from molgym_amd import observations as om
+from molgym_amd.synthetic import CONFIGS, make_batch
+om._NATIVE = _obsparse
+for name, n in (('cfg2', 140), ('cfg3', 33), ('cfg5', 9)):
+    cfg = CONFIGS[name]
+    obs = list(make_batch(n, cfg['canvas_size'], cfg['zs'], seed=n)['obs'])
+    obs[1] = ([[np.int64(l), [np.float64(c) for c in p]] for l, p in obs[1][0]], list(obs[1][1]))
+    got = om.ParsedObservations.from_list(obs)
+    om._NATIVE = None
+    ref = om.ParsedObservations.from_list(obs)
+    om._NATIVE = _obsparse
+    assert np.array_equal(got.labels, ref.labels) and np.array_equal(got.xyz, ref.xyz) and np.array_equal(got.bags, ref.bags)
+    bad = [[obs[0], (obs[1][0][:3], obs[1][1])], [obs[0], (obs[1][0], obs[1][1][:1])], [obs[0], None], [obs[0], (None, None)],
+           [obs[0], ([(0, (0.0, 0.0))] * len(obs[0][0]), obs[0][1])], [obs[0], ([('x', (0.0, 0.0, 0.0))] * len(obs[0][0]), obs[0][1])]]
+    for b in bad:
+        try:
+            om.ParsedObservations.from_list(b)
+        except Exception:
+            pass
+        else:
+            raise SystemExit('irregular input was accepted')
+print('asan clean')
+'''
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', PYTHONMALLOC='malloc')
+    r = subprocess.run([sys.executable, '-c', script, root, str(pkg)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and 'asan clean' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-4000:]

@@ -1,3 +1,4 @@
+// build (GPU box): /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/probe/graph_race.hip -o tools/probe/graph_race
 // probe (GPU box): is it safe to update the parameters of a hipGraphExec's kernel nodes while earlier launches of the SAME
 // exec are still queued / running?  Each replay r writes (r + 0.5) into slot r from a slow kernel; the host updates and launches
 // 200 replays back to back without synchronising.  Any slot that does not hold its own value means the arguments of a launch in

@@ -1,3 +1,4 @@
+// build (GPU box): /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/probe/graph_update.hip -o tools/probe/graph_update
 // probe (GPU box): what does replaying a linear hipGraph of N kernel nodes cost on the host when EVERY node's parameters
 // (grid + arguments) are updated before each launch (hipGraphExecKernelNodeSetParams), against N plain launches?
 #include <hip/hip_runtime.h>
