@@ -94,22 +94,55 @@ def _algorithmic_bytes(name, natoms, num_zs):
     return None
 
 
-def _pmc_traffic(config, name):
+def sources_sha16():
+    """sha256 (first 16 hex digits) over the library's sources: what a PMC summary was measured on, and what runs now"""
+    import hashlib
+    d = os.path.join(ROOT, 'molgym_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.inc', '.h')) and f != 'cg_tables.inc':
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_file(config):
     path = os.path.join(ROOT, 'profiles', f'pmc_{config}.json')
-    if not os.path.exists(path):
+    return (path, json.load(open(path))) if os.path.exists(path) else (path, None)
+
+
+def pmc_source(config):
+    """where the line's HBM byte counts come from: they are REPLAYED from the committed rocprofv3 --pmc summary of the same config
+    (tools/artifacts.sh -> tools/pmc_summary.py; counters need their own profiler passes), not measured in the bench run itself.
+    `stale` says whether the kernels have changed since that summary was taken."""
+    import hashlib
+    path, rec = _pmc_file(config)
+    if rec is None:
         return None
-    return json.load(open(path)).get(name, {}).get('hbm_bytes_per_launch')
+    meta = rec.get('_meta', {})
+    now = sources_sha16()
+    return {'file': os.path.relpath(path, ROOT), 'file_sha16': hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16],
+            'measured_in_this_run': False, 'collected': meta.get('collected'), 'sources_sha16_at_collection': meta.get('sources_sha16'),
+            'sources_sha16_now': now, 'stale': meta.get('sources_sha16') != now,
+            'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only), x2 gfx950 FETCH correction'}
+
+
+def _pmc_traffic(config, name):
+    rec = _pmc_file(config)[1]
+    if rec is None:
+        return None
+    return rec.get(name, {}).get('hbm_bytes_per_launch')
 
 
 def step_hbm(config, ms_per_step):
     """whole-step HBM traffic from the PMC summary of the same config (`_step` record of tools/pmc_summary.py) against
     the live step time: {'hbm_bytes_per_step', 'hbm_gbps', 'hbm_frac'} (None without that file)"""
-    path = os.path.join(ROOT, 'profiles', f'pmc_{config}.json')
-    rec = json.load(open(path)).get('_step') if os.path.exists(path) else None
+    rec = (_pmc_file(config)[1] or {}).get('_step')
     if not rec:
-        return {'hbm_bytes_per_step': None, 'hbm_gbps': None, 'hbm_frac': None}
+        return {'hbm_bytes_per_step': None, 'hbm_gbps': None, 'hbm_frac': None, 'hbm_bytes_source': None}
     gbps = rec['hbm_bytes_per_step'] / (ms_per_step * 1e-3) / 1e9
-    return {'hbm_bytes_per_step': rec['hbm_bytes_per_step'], 'hbm_gbps': gbps, 'hbm_frac': gbps / PEAK_HBM_GBPS}
+    return {'hbm_bytes_per_step': rec['hbm_bytes_per_step'], 'hbm_gbps': gbps, 'hbm_frac': gbps / PEAK_HBM_GBPS,
+            'hbm_bytes_source': 'replayed: see roofline.traffic_source'}
 
 
 def family_rooflines(per_step_ms, natoms, num_zs):
@@ -147,7 +180,7 @@ def dominant_kernel_roofline(ac, batch, natoms, cfg, config_name='cfg2'):
     traffic = _pmc_traffic(config_name, name)
     alg_bytes = _algorithmic_bytes(name, natoms, len(cfg['zs']))
     out = {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': PEAK_F32_TFLOPS, 'kernel': name, 'kernel_avg_ms': ms,
-           'launches_per_step': spans[name][1], 'traffic': traffic,
+           'launches_per_step': spans[name][1], 'traffic': traffic, 'traffic_source': pmc_source(config_name),
            'note': 'f32 kernel: neighbour contractions on v_mfma_f32_16x16x4_f32 (dense f32 MFMA peak 157.3 TFLOP/s == '
                    'the f32 vector peak on gfx950), sparse CG projection on the vector ALUs; achieved / frac use the '
                    'DENSE-CG algorithmic count of SURVEY 8(d), achieved_executed / frac_executed the useful flops of '

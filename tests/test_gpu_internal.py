@@ -42,14 +42,15 @@ def test_vectorised_zmat_matches_scalar_helper(built_lib):
         np.testing.assert_allclose(got[b], want, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize('canvas,width', [(7, 128), (12, 128), (20, 128), (7, 64)])
-def test_outputs_and_gradients_match_oracle(built_lib, canvas, width):
+@pytest.mark.parametrize('canvas,width,B', [(7, 128, 24), (12, 128, 24), (20, 128, 24), (7, 64, 24), (7, 128, 140)])
+def test_outputs_and_gradients_match_oracle(built_lib, canvas, width, B):
     """(7, 128) and (12, 128): the SchNet interactions as one launch per direction, 8- and 16-atom layouts (schnet_fused.inc);
-    (20, 128) and (7, 64): the per-layer launches (molecules above 16 atoms; atom features other than 64)"""
+    (20, 128) and (7, 64): the per-layer launches (molecules above 16 atoms; atom features other than 64); (7, 128, 140):
+    BASELINE configs[0] at its real mini-batch size (the sort and the weight-gradient row-chunk classes depend on B)"""
     ac, ref = _pair(0, width, canvas)
-    data = make_batch_internal(24, canvas, ZS, seed=4)
+    data = make_batch_internal(B, canvas, ZS, seed=4)
     g = torch.Generator().manual_seed(1)
-    wl, we, wv = (torch.randn(24, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
+    wl, we, wv = (torch.randn(B, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
     out = ac.step(data['obs'], data['act'])
     (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
     torch.cuda.synchronize()
@@ -90,7 +91,7 @@ def test_graph_step_equals_stream_launches(built_lib):
     bit for bit, gradient to the reproducibility of its float atomics), for mini-batches of different ragged sizes through the
     same cached graph"""
     ac, ref = _pair(6)
-    for k, B in enumerate((20, 33, 7)):
+    for k, B in enumerate((20, 33, 7, 140)):  # (140: BASELINE configs[0]'s mini-batch, what bench.py --agent internal times)
         d = make_batch_internal(B, N, ZS, seed=10 + k)
         batch = ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret'])
         res = {}

@@ -96,6 +96,39 @@ def test_gradient_is_additive_over_shards_at_full_size(built_lib, name):
     assert (ac.theta.grad - whole).abs().max().item() < 2e-4 * whole.abs().max().item()
 
 
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4', 'cfg5'])
+def test_masked_oracle_comparison_at_full_size(built_lib, name):
+    """The float64 oracle AT BASELINE's full sizes (B = 1024 / 1024 / 2048), through a mask: the samples of a mini-batch are
+    independent (ppo.py:36-42: every term of the loss is a mean over samples of per-sample quantities), so the HIP path runs the
+    FULL batch -- every size-selected kernel: dw4, sx / pk, the tiled level-0 adjoint, the one-workgroup heads backward, the
+    side stream -- with the output adjoint zero outside 16 random samples, and the oracle runs those 16 samples only.  Their
+    logp / ent / v must agree to 1e-5 and the full-batch gradient must be the oracle's gradient of the 16 (2e-4 of the slot
+    maximum, 1e-2 per entry above 1 % of it): what the other samples leak into the gradient is an error like any other."""
+    from tests.helpers import assert_grads, grad_report, make_pair, rel_err
+    ac, ref, cfg = make_pair(name, seed=4)
+    B = cfg['batch']
+    data = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=12)
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(B, size=16, replace=False))
+    g = torch.Generator().manual_seed(6)
+    w16 = torch.randn(3, 16, generator=g, dtype=torch.float64) * torch.tensor([[1.0], [0.3], [0.7]], dtype=torch.float64)
+    w = torch.zeros(3, B, dtype=torch.float64)
+    w[:, torch.from_numpy(pick)] = w16
+    out = ac.step(data['obs'], data['act'])
+    wd = w.cuda()
+    (out['logp'].double() * wd[0] + out['ent'].double() * wd[1] + out['v'].double() * wd[2]).sum().backward()
+    torch.cuda.synchronize()
+    obs16, act16 = [data['obs'][i] for i in pick], np.asarray(data['act'])[pick]
+    exp = ref.step(obs16, act16, dtype=torch.float64)
+    (exp['logp'] * w16[0] + exp['ent'] * w16[1] + exp['v'] * w16[2]).sum().backward()
+    sel = torch.from_numpy(pick)
+    for k in ('logp', 'ent', 'v'):
+        got = out[k].detach().cpu()[sel]
+        assert rel_err(got, exp[k].detach()) < 1e-5, (k, rel_err(got, exp[k].detach()))
+    assert torch.isfinite(out['logp']).all() and torch.isfinite(out['v']).all()
+    assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
+
+
 def _run_worker(name, env_extra, path):
     env = dict(os.environ)
     env.update(env_extra)

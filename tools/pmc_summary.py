@@ -54,8 +54,13 @@ def main():
     if steps > 0:
         total = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in out.values() if 'hbm_bytes_per_launch' in v)
         out['_step'] = {'steps_in_run': steps, 'hbm_bytes_per_step': total / steps}
+    # what the counters were measured on (bench.py's roofline.traffic_source compares it with the sources of the run that replays them)
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from molgym_amd.profile import sources_sha16
+    out['_meta'] = {'sources_sha16': sources_sha16(), 'collected': time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}
     json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
-    top = sorted((kv for kv in out.items() if 'hbm_bytes_per_launch' in kv[1] and 'launches' in kv[1]),
+    top = sorted((kv for kv in out.items() if isinstance(kv[1], dict) and 'hbm_bytes_per_launch' in kv[1] and 'launches' in kv[1]),
                  key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]
     for k, v in top:
         print(f"{k:40s} launches={v['launches']:5d} bytes/launch={v['hbm_bytes_per_launch'] / 1e6:9.3f} MB")
