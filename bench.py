@@ -273,6 +273,8 @@ def main():
         args.steps = -(-args.steps // quantum) * quantum
         args.warmup = -(-max(args.warmup, 1) // world) * world
 
+    # MG_EPOCH_CACHE=0: derived weights and the fold of the expanded weight gradients per mini-batch (the round-4 step; A/B)
+    epoch_cache = os.environ.get('MG_EPOCH_CACHE', '1') != '0'
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)] if args.inflight > 1 else None
     counter = [0]
 
@@ -286,24 +288,32 @@ def main():
                 # epoch's mini-batches accumulate (ppo.py:117-131).  (Through round 2 the one-GPU run zeroed before every step
                 # -- one extra 4 us launch per step that the product does not make and that the N > 1 runs never had.)
                 ac.theta.grad.zero_()
+                # ... and steps the optimizer once per epoch (ppo.py:145): what depends on theta alone (the derived weight matrices)
+                # is prepared by the epoch's first mini-batch and reused by the others, as ppo.train does (epoch_cache)
+                ac.invalidate_weights()
             mine = args.scaling == 'weak' or i % world == rank
             if mine:
-                last_stats[0] = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale)
-            if use_dist and ((i + 1) % every == 0 or last):
-                dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL / xGMI per epoch
-                n_allreduce[0] += 1
+                last_stats[0] = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, epoch_cache=epoch_cache)
+            if (i + 1) % every == 0 or last:
+                ac.fold_gradients()  # the epoch's expanded complex weight gradients -> theta.grad (once per epoch, like the all-reduce)
+                if use_dist:
+                    dist.all_reduce(ac.theta.grad)  # one flat f32 bucket over RCCL / xGMI per epoch
+                    n_allreduce[0] += 1
             return last_stats[0]
         # epoch semantics of ppo.train: gradients of independent mini-batches accumulate; they are issued
         # round-robin on `inflight` streams with their own workspaces
         k = counter[0] % len(streams)
+        if counter[0] % every == 0:
+            ac.invalidate_weights()
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
-            return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, slot=k)
+            return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, slot=k, epoch_cache=epoch_cache)
 
     def drain():
         if streams is not None:
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
+            ac.fold_gradients()
             if use_dist:
                 dist.all_reduce(ac.theta.grad)
 
@@ -364,12 +374,15 @@ def main():
         ep_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
         def ep_step(i):
+            if i % every == 0:
+                ac.invalidate_weights()
             with torch.cuda.stream(ep_streams[i % 3]):
-                return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, slot=i % 3)
+                return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, slot=i % 3, epoch_cache=epoch_cache)
 
         def ep_drain():
             for st in ep_streams:
                 torch.cuda.current_stream().wait_stream(st)
+            ac.fold_gradients()
 
         for st in ep_streams:
             st.wait_stream(torch.cuda.current_stream())
@@ -449,6 +462,11 @@ def main():
                        'step_frac_ragged': f_ragged * value / 1e12 / (PEAK_F32_TFLOPS * world),
                        'allreduce_every_steps': every if use_dist else None,
                        'zero_grad_every_steps': every,
+                       # per epoch of `every` mini-batches, not per mini-batch (theta is constant over an epoch, ppo.py:117-146):
+                       # the derived weight matrices are re-derived and the expanded complex weight gradients folded into the
+                       # gradient at this cadence -- INSIDE the timed region, like the zero and the all-reduce
+                       'derived_weights_every_steps': every if epoch_cache else 1,
+                       'gradient_fold_every_steps': every if epoch_cache else 1,
                        'steps_requested': steps_asked,
                        'steps_note': None if steps_asked == args.steps else
                        f'--steps {steps_asked} rounded up to {args.steps} = a multiple of world x allreduce_every '

@@ -58,8 +58,8 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step; 7: mg_cov_build_params (num_cg_levels a build parameter).  */
-#define MG_ABI_VERSION 7
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step; 7: mg_cov_build_params (num_cg_levels a build parameter); 8: mg_cov_ppo_step takes `flags`, mg_cov_fold_grads, derived weights first in the workspace.  */
+#define MG_ABI_VERSION 8
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
@@ -212,12 +212,24 @@ int mg_ppo_loss(int32_t B, const float* pred, const double* old_logp, const doub
  * ONE hipGraphLaunch is issued -- ~30 us of host time instead of ~250 (the update loop is host-bound otherwise).  Mini-batches
  * in flight on different streams must use different slots.  Falls back to the stream launches by itself where a graph cannot
  * express the step (side streams of the large configurations); *used_graph_host (may be NULL) reports which form ran.
- * MG_GRAPH=0 in the environment disables the graph form.                                                              */
+ * MG_GRAPH=0 in the environment disables the graph form.
+ * flags (theta is constant over the mini-batches of a PPO epoch -- the reference steps the optimizer once per epoch,
+ * ppo.py:117-146 -- so what depends on theta alone need not be redone per mini-batch):
+ *   MG_STEP_WEIGHTS_CURRENT  the derived weight matrices in THIS workspace (they sit first in it, at offsets that do not depend on
+ *                            the mini-batch) were written by an earlier call with the same theta: skip their preparation;
+ *   MG_STEP_DEFER_FOLD       leave the expanded complex weight gradients accumulating in the workspace instead of folding them
+ *                            into grad_theta at the end of the step; the caller folds once per epoch with mg_cov_fold_grads
+ *                            (before it reads grad_theta) -- one fold per workspace used.                                      */
+#define MG_STEP_WEIGHTS_CURRENT 1
+#define MG_STEP_DEFER_FOLD 2
 int mg_cov_ppo_step(const mg_cov_cfg* cfg, const float* theta, const float* pos, const int32_t* charges, const float* bags,
                     const float* actions, const float* lebedev, void* workspace, size_t workspace_bytes,
                     const double* old_logp, const double* adv, const double* ret, double clip_ratio, double vf_coef,
                     double entropy_coef, double loss_scale, float* out, float* gout, double* stats, double* stats_accum,
-                    float* grad_theta, int32_t graph_slot, int32_t* used_graph_host, void* stream);
+                    float* grad_theta, int32_t graph_slot, int32_t flags, int32_t* used_graph_host, void* stream);
+/* grad_theta += the expanded complex weight gradients a workspace accumulated over mg_cov_ppo_step(.., MG_STEP_DEFER_FOLD) calls
+ * (and the accumulator is left zero): the per-epoch half of what mg_cov_backward does at the end of every call.             */
+int mg_cov_fold_grads(const mg_cov_cfg* cfg, void* workspace, size_t workspace_bytes, float* grad_theta, void* stream);
 
 /* the same for the internal-coordinate agent (mg_int_forward + mg_ppo_loss + mg_int_backward) */
 int mg_int_ppo_step(const mg_int_cfg* cfg, const float* theta, const int32_t* mol_off, const int32_t* edge_off,

@@ -296,18 +296,41 @@ class CovariantAC(FlatThetaAgent):
         d_pos, d_chg, d_bag, d_act = self._upload_packed(pos, charges, bags, acts)
         return RolloutOnDevice(self, natoms, d_pos, d_chg, d_bag, d_act, f64(data['logp']), f64(data['adv']), f64(data['ret']))
 
-    def _workspace(self, cfg: _lib.CovCfg, slot: int = 0) -> torch.Tensor:
+    def _workspace(self, cfg: _lib.CovCfg, slot: int = 0, epoch_step: bool = False) -> torch.Tensor:
         nbytes = C.c_size_t()
         self._chk(self._L().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         cache = self.__dict__.setdefault('_ws_cache', {})
         ws = cache.get(slot)
+        if not epoch_step and self.__dict__.get('_ws_epoch', {}).get(slot, {}).get('pending'):
+            self.fold_gradients()  # another kind of call on a workspace that still holds an epoch's deferred weight gradients
         if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
+            if self.__dict__.get('_ws_epoch', {}).get(slot, {}).get('pending'):
+                self.fold_gradients()  # (the block is about to be replaced)
             ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
             cache[slot] = ws
+            self.__dict__.setdefault('_ws_epoch', {}).pop(slot, None)
         # the cached block may have been allocated under another stream (rollout: default stream; ppo.train: its own): tell
         # the caching allocator about THIS use, so that a later replacement is not handed out while kernels still read it
         ws.record_stream(torch.cuda.current_stream(self.theta.device))
         return ws
+
+    # ---- what depends on theta alone, once per EPOCH instead of once per mini-batch (ppo.py:117-146: one optimizer step per epoch) ----
+    def invalidate_weights(self) -> None:
+        """theta may have changed (start of a PPO epoch): the derived weight matrices cached in the workspaces are stale"""
+        for st in self.__dict__.get('_ws_epoch', {}).values():
+            st['weights'] = False
+
+    def fold_gradients(self) -> None:
+        """mg_cov_fold_grads for every workspace whose mini-batches ran with `epoch_cache=True` since the last fold: theta.grad is
+        complete only after this (ppo.train calls it once per epoch, before the all-reduce / norm / clip / Adam step).  Issued on
+        the current stream, which must already be ordered behind the mini-batches' streams (ppo._DeviceRunner.end_epoch)."""
+        for slot, st in self.__dict__.get('_ws_epoch', {}).items():
+            if st.get('pending'):
+                ws = self._ws_cache[slot]
+                with self._guard():
+                    self._chk(self._L().mg_cov_fold_grads(C.byref(st['cfg']), _ptr(ws), ws.numel(), _ptr(self.theta.grad), self._s()))
+                ws.record_stream(torch.cuda.current_stream(self.theta.device))
+                st['pending'] = False
 
     def forward_batch(self, batch: 'DeviceBatch', slot: int = 0) -> torch.Tensor:
         """(3, B) float32: logp, ent, v -- no autograd graph."""
@@ -365,7 +388,7 @@ class CovariantAC(FlatThetaAgent):
 
     def ppo_minibatch(self, batch: 'DeviceBatch', clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0, stats_accum: Optional[torch.Tensor] = None,
-                      graph: Optional[bool] = None) -> torch.Tensor:
+                      graph: Optional[bool] = None, epoch_cache: bool = False) -> torch.Tensor:
         """One compute_loss forward + backward (molgym/ppo.py:124-131) entirely on the device, ONE C call (mg_cov_ppo_step):
         step -> float64 PPO loss -> hand-written backward, gradients ACCUMULATED (atomically) into theta.grad.
         Returns the 6 float64 loss statistics (device tensor, no sync); `stats_accum` (6 float64, optional) additionally gets
@@ -374,9 +397,19 @@ class CovariantAC(FlatThetaAgent):
         can be in flight on several HIP streams.  `graph` (default: on, MG_GRAPH=0 in the environment turns it off): the ~27
         launches of the step are recorded and issued as one hipGraph launch whose kernel nodes are updated in place
         (include/molgym_hip.h: the update loop is otherwise bound by the host's launch rate); the library falls back to plain
-        stream launches where a graph cannot express the step."""
+        stream launches where a graph cannot express the step.  `epoch_cache` (ppo.train's loop): theta is constant over the
+        mini-batches of an epoch, so the derived weight matrices of this slot's workspace are prepared by the slot's FIRST
+        mini-batch after `invalidate_weights()` only, and the expanded complex weight gradients stay in the workspace until
+        `fold_gradients()` -- theta.grad is incomplete until then."""
         lib = self._L()
-        ws = self._workspace(batch.cfg, slot)
+        ws = self._workspace(batch.cfg, slot, epoch_step=epoch_cache)
+        flags = 0
+        if epoch_cache:
+            st = self.__dict__.setdefault('_ws_epoch', {}).setdefault(slot, {'weights': False, 'pending': False})
+            flags = _lib.STEP_DEFER_FOLD | (_lib.STEP_WEIGHTS_CURRENT if st['weights'] else 0)
+            st.update(weights=True, pending=True, cfg=batch.cfg)
+        else:
+            self.__dict__.get('_ws_epoch', {}).pop(slot, None)  # (this call re-prepares the weights and zeroes the accumulator)
         B = batch.cfg.B
         dev = self.theta.device
         out = torch.empty(3, B, dtype=torch.float32, device=dev)
@@ -391,7 +424,7 @@ class CovariantAC(FlatThetaAgent):
                                           _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
                                           _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef, entropy_coef,
                                           float(loss_scale), _ptr(out), _ptr(gout), _ptr(stats), _ptr(stats_accum),
-                                          _ptr(self.theta.grad), slot if use_graph else -1, C.byref(used), self._s()))
+                                          _ptr(self.theta.grad), slot if use_graph else -1, flags, C.byref(used), self._s()))
         self._last_ws, self._last_cfg, self._last_out = ws, batch.cfg, out
         self.last_step_used_graph = bool(used.value)
         self.__dict__.setdefault('_unchecked', {})[slot] = (batch.cfg, ws)

@@ -208,7 +208,7 @@ struct SampleCtx {
 static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float* pos, const int32_t* charges,
                             const float* bags, float* actions, const float* leb, void* ws, size_t ws_bytes,
                             float* out, void* stream, const SampleCtx* smp, const PpoLossArgs* loss = nullptr,
-                            bool* loss_fused = nullptr) {
+                            bool* loss_fused = nullptr, int step_flags = 0) {
   PLayout P;
   int rc = build_layout(c, &P);
   if (rc) return rc;
@@ -230,14 +230,36 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   // the derived weight matrices (and the zero of the expanded weight-gradient scratch the backward accumulates
   // into) do not depend on the batch: side stream, beside the list / geometry kernels
   hipEvent_t weights_ready = nullptr;
-  bool lists_done = false;
+  bool lists_done = false, front_lists = false;
+  // MG_STEP_WEIGHTS_CURRENT: the derived weights of this workspace were written by an earlier step with the same theta (they sit
+  // at batch-independent offsets, ws_build) and the expanded weight gradients are either zero (the last fold left them so) or
+  // still accumulating (MG_STEP_DEFER_FOLD): neither is touched here
+  const bool weights_current = (step_flags & MG_STEP_WEIGHTS_CURRENT) != 0;
   {
-    hipStream_t ss = side_fork(s);
+    hipStream_t ss = weights_current ? s : side_fork(s);
     if (ss == s) {
       // one launch: derived weights, zero of dwexp and of the error flags -- and, on small mini-batches, the list build
       const ListsJob lj = {charges, B, N, TA, TE};
       lists_done = (B <= MG_LISTS_SMALL_B && N <= 16);
-      RC(prep_weights(s, theta, w, true, lists_done ? &lj : nullptr));
+      // ... unless the first fused kernel builds them itself (k_level0_fwd<true>: the list build as its workgroup 0, the atom
+      // workgroups deriving their own descriptors): then NOTHING precedes that launch.  MG_FRONT_LISTS=0: the separate launch (A/B)
+      static int front_on = -1;
+      if (front_on < 0) { const char* e = getenv("MG_FRONT_LISTS"); front_on = e ? atoi(e) : 1; }
+      front_lists = weights_current && lists_done && front_on && !smp && level0_fused(true, c, w);
+      if (!weights_current) RC(prep_weights(s, theta, w, true, lists_done ? &lj : nullptr));
+      else if (front_lists) {
+      } else if (lists_done) {
+        WPrepArgs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(k_prep_lists, dim3(1, 1), dim3(1024), 0, s, none, 0, lj.charges, lj.B, lj.N, lj.TA, lj.TE, w.L);
+        LAUNCH_CHECK();
+      } else {  // (a kernel, not a memset: the step may be being recorded into a graph)
+        WPrepArgs none;
+        memset(&none, 0, sizeof(none));
+        none.zero_i4 = w.L.err;
+        hipLaunchKernelGGL(k_prep_weights, dim3(1, 1), dim3(64), 0, s, none);
+        LAUNCH_CHECK();
+      }
     } else {
       RC(prep_weights(ss, theta, w));
       HIP_CHECK(hipMemsetAsync(w.dwexp_all, 0, w.dwexp_floats * sizeof(float), ss));
@@ -291,8 +313,11 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       if (w.ld_e[1][l] != la.ld_E0 || w.ld_e[2][l] != la.ld_rad2)
         MG_FAIL(MG_EINVAL, "level-0 kernel: unexpected row strides");
     }
+    la.B = B; la.cfgTA = TA; la.cfgTE = TE;
     ProfScope prof(s, "k_level0");
-    hipLaunchKernelGGL(k_level0_fwd, dim3(TA), dim3(L0_T), 0, s, la, w.L);
+    if (front_lists && N <= 8) hipLaunchKernelGGL((k_level0_fwd<true, 8>), dim3(TA + 1), dim3(L0_T), 0, s, la, w.L);
+    else if (front_lists) hipLaunchKernelGGL((k_level0_fwd<true, L0_MAXN>), dim3(TA + 1), dim3(L0_T), 0, s, la, w.L);
+    else hipLaunchKernelGGL((k_level0_fwd<false, L0_MAXN>), dim3(TA), dim3(L0_T), 0, s, la, w.L);
     LAUNCH_CHECK();
     input_done = true;
   } else if (TE > 0) {
@@ -647,8 +672,9 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
                                const float* actions, const float* leb, void* ws, size_t ws_bytes, const double* old_logp,
                                const double* adv, const double* ret, double clip_ratio, double vf_coef, double entropy_coef,
                                double loss_scale, float* out, float* gout, double* stats, double* stats_accum,
-                               float* grad_theta, int32_t graph_slot, int32_t* used_graph, void* stream) {
+                               float* grad_theta, int32_t graph_slot, int32_t flags, int32_t* used_graph, void* stream) {
   if (!c || !out || !gout || !stats || !grad_theta) MG_FAIL(MG_EINVAL, "mg_cov_ppo_step: null argument");
+  if (flags & ~(MG_STEP_WEIGHTS_CURRENT | MG_STEP_DEFER_FOLD)) MG_FAIL(MG_EINVAL, "mg_cov_ppo_step: unknown flags %d", flags);
   hipStream_t s = (hipStream_t)stream;
   static int fuse_loss = -1;
   if (fuse_loss < 0) { const char* e = getenv("MG_FUSED_LOSS"); fuse_loss = e ? atoi(e) : 1; }
@@ -656,14 +682,15 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
     const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum};
     bool fused = false;
     int rc = cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream, nullptr,
-                              fuse_loss ? &la : nullptr, &fused);
+                              fuse_loss ? &la : nullptr, &fused, flags);
     if (rc) return rc;
     if (!fused) {  // (staged heads: the loss as its own launch)
       hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
                          entropy_coef, stats, gout, loss_scale, stats_accum);
       LAUNCH_CHECK();
     }
-    return mg_cov_backward(c, theta, pos, charges, bags, actions, leb, ws, ws_bytes, gout, grad_theta, stream);
+    return cov_backward_impl(c, theta, pos, charges, bags, actions, leb, ws, ws_bytes, gout, grad_theta, stream,
+                             (flags & MG_STEP_DEFER_FOLD) != 0);
   };
   if (used_graph) *used_graph = 0;
   static int graphs_on = -1;
@@ -678,7 +705,7 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
     g_rec.end();
     if (rc) return rc;
     if (!g_rec.unsupported && !g_rec.recs.empty()) {
-      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][0][graph_slot], s);
+      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][0][graph_slot + ((flags & MG_STEP_WEIGHTS_CURRENT) ? MG_GRAPH_SLOTS : 0)], s);
       if (e == hipSuccess) {
         if (used_graph) *used_graph = 1;
         return MG_OK;
@@ -689,6 +716,21 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
     }
   }
   return run();
+}
+
+// the per-epoch half of the backward: fold the expanded complex weight gradients a workspace accumulated (MG_STEP_DEFER_FOLD)
+extern "C" int mg_cov_fold_grads(const mg_cov_cfg* c, void* ws, size_t ws_bytes, float* grad_theta, void* stream) {
+  if (!c || !ws || !grad_theta) MG_FAIL(MG_EINVAL, "mg_cov_fold_grads: null argument");
+  PLayout P;
+  int rc = build_layout(c, &P);
+  if (rc) return rc;
+  WS w;
+  rc = ws_build(c, P, ws, &w, nullptr);
+  if (rc) return rc;
+  if (ws_bytes < w.bytes) MG_FAIL(MG_ENOMEM, "workspace %zu bytes < required %zu", ws_bytes, w.bytes);
+  rc = check_device_of(grad_theta, "grad_theta");
+  if (rc) return rc;
+  return launch_fold_weights((hipStream_t)stream, w, grad_theta);
 }
 
 // the same for the internal-coordinate (SchNet) actor-critic: mg_int_forward + mg_ppo_loss + mg_int_backward in one call and,

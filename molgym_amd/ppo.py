@@ -135,6 +135,9 @@ class _DeviceRunner:
         # loss kernel): no tensor per mini-batch, no `stats * scale` launch per mini-batch
         import inspect
         self._accumulates = 'stats_accum' in inspect.signature(ac.ppo_minibatch).parameters
+        # agents that keep what depends on theta alone across the mini-batches of an epoch (CovariantAC: derived weights prepared once
+        # per epoch and workspace, expanded weight gradients folded once per epoch): theta only changes between epochs here
+        self._epoch_cache = 'epoch_cache' in inspect.signature(ac.ppo_minibatch).parameters and hasattr(ac, 'fold_gradients')
         self._acc = None
 
     def set_epoch(self, locals_: Sequence[np.ndarray]):
@@ -155,6 +158,8 @@ class _DeviceRunner:
                 p.grad = torch.zeros_like(p)
         if self._accumulates:
             self._acc = torch.zeros(6, dtype=torch.float64, device=self.dev)  # (on the current stream, ahead of the waits below)
+        if self._epoch_cache:
+            self.ac.invalidate_weights()  # the optimizer stepped since the last epoch
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(self.dev))  # (also orders the index upload before the gathers)
 
@@ -176,6 +181,8 @@ class _DeviceRunner:
         if len(local) == 0:  # this rank's slice of a small remainder mini-batch
             return torch.zeros(6, dtype=torch.float64, device=self.dev)
         kw = {'stats_accum': self._acc} if self._accumulates else {}
+        if self._epoch_cache:
+            kw['epoch_cache'] = True
         if not self.streams:
             stats = self.ac.ppo_minibatch(self._minibatch(mb_index, local), *self.hp, loss_scale=scale, **kw)
             if self._accumulates:
@@ -196,6 +203,8 @@ class _DeviceRunner:
     def end_epoch(self):
         for st in self.streams:
             torch.cuda.current_stream(self.dev).wait_stream(st)
+        if self._epoch_cache:
+            self.ac.fold_gradients()  # theta.grad is complete from here on (all-reduce / norm / clip / Adam follow)
 
     def accumulated(self) -> Optional[torch.Tensor]:
         """sum over this rank's mini-batches of (share x statistics), where the agent accumulated it on the device"""

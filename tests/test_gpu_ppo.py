@@ -169,6 +169,48 @@ def test_graph_step_equals_stream_launches(built_lib):
         assert abs(out[True][1][k] - out[False][1][k]) <= 1e-6 * max(1.0, abs(out[False][1][k])), k
 
 
+def test_epoch_cache_equals_per_minibatch_preparation(built_lib):
+    """What depends on theta alone, once per EPOCH (mg_cov_ppo_step flags MG_STEP_WEIGHTS_CURRENT / MG_STEP_DEFER_FOLD +
+    mg_cov_fold_grads; theta is constant over an epoch's mini-batches, ppo.py:117-146) == the same mini-batches each preparing the
+    derived weights and folding the expanded weight gradients itself: per-step statistics and outputs bit for bit, the epoch's
+    gradient to the reproducibility of its float atomics -- for mini-batches of different ragged sizes through ONE workspace
+    (the derived weights sit at batch-independent offsets), graph and stream form, and across a change of theta."""
+    ac, ref, cfg = make_pair('cfg2', seed=31)
+    sizes = (24, 31, 9, 140, 24)
+    batches = []
+    for k, B in enumerate(sizes):
+        d = make_batch(B, cfg['canvas_size'], cfg['zs'], seed=70 + k)
+        batches.append(ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret']))
+    for graph in (True, False):
+        for epoch in range(2):
+            res = {}
+            for cached in (False, True):
+                ac.theta.grad = torch.zeros_like(ac.theta)
+                ac.invalidate_weights()
+                outs = []
+                for b in batches:
+                    st = ac.ppo_minibatch(b, 0.2, 0.5, 0.01, loss_scale=0.5, graph=graph, epoch_cache=cached)
+                    outs.append((st.clone(), ac._last_out.clone()))
+                if cached:
+                    state = ac._ws_epoch[0]
+                    assert state['weights'] and state['pending']
+                    ac.fold_gradients()
+                    assert not ac._ws_epoch[0]['pending']
+                torch.cuda.synchronize()
+                res[cached] = (outs, ac.theta.grad.clone())
+            for (s0, o0), (s1, o1) in zip(res[False][0], res[True][0]):
+                assert torch.equal(s0, s1) and torch.equal(o0, o1)
+            g0, g1 = res[False][1], res[True][1]
+            assert torch.isfinite(g1).all() and (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
+            # every slot of the gradient is there (a missing fold would leave the complex mixes' slots at zero)
+            for name, (off, shape) in ac.slot_table.items():
+                n = int(np.prod(shape))
+                if g0[off:off + n].abs().max().item() > 0:
+                    assert g1[off:off + n].abs().max().item() > 0, name
+            with torch.no_grad():  # "the optimizer steps": the next epoch must see the new theta
+                ac.theta.add_(0.01 * torch.randn_like(ac.theta))
+
+
 def test_runahead_epochs_equal_synchronous_loop(built_lib, monkeypatch):
     """ppo.train with the KL test / norm / clip on the device and the next epoch issued before the previous one's record is read
     (molgym_amd/ppo.py::_train_runahead) == the loop that synchronises every epoch like the reference (ppo.py:133-146): same
