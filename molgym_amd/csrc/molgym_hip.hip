@@ -200,6 +200,17 @@ static int prep_weights(hipStream_t s, const float* theta, WS& w, bool zero_scra
   return MG_OK;
 }
 
+// [r5] the atom cat-mix of level k as the epilogue of k_catbuild_mfma (cg_mfma.inc: CgMix): MG_CATMIX_EPI=1.  Off by default: measured
+// neutral on the SF6 mini-batch (0.3770 vs 0.3767 ms) and its float atomics cost the forward outputs their bit-for-bit repeatability
+static bool catmix_epilogue(const WS& w, const PLayout& P, int k) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MG_CATMIX_EPI"); on = e ? atoi(e) : 0; }
+  if (!on || k < 1 || P.atom_cout[k] > 16) return false;  // (one output per lane quad)
+  for (int l = 0; l < 5; ++l)
+    if (w.atom[k][l].b_off >= 0 || !w.atom[k][l].cplx || w.atom[k][l].perm_n != 2 * kNblk[l] + 1) return false;
+  return true;
+}
+
 struct SampleCtx {
   RngKey seed;
   int mode;
@@ -383,6 +394,10 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       }
       ea.ld_row = EL_K; ea.ld_out = (k < NLEV - 1) ? w.ld_e[k + 1][0] : 2 * CH; ea.ldb = w.edge[k][0].ldb;
       ea.em = w.em; ea.Acm = w.Acm[k]; ea.TA = TA; ea.N = N;
+      if (!smp && catmix_epilogue(w, P, k)) {
+        for (int l = 0; l < 5; ++l) ea.zA[l] = w.A[k + 1][l];
+        ea.zld = 2 * P.atom_cout[k];
+      }
       ProfScope prof(s, "k_edge_level");
       hipLaunchKernelGGL(k_edge_fwd, dim3(TA), dim3(EL_T), el_fwd_lds_bytes(N), s, ea, w.L);
       LAUNCH_CHECK();
@@ -455,8 +470,18 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       for (int l = 0; l < 5; ++l) A.p[l] = w.A[k][l];
       A.C = CH;
       ProfScope prof(s, "k_catbuild_mfma");
-      hipLaunchKernelGGL(k_catbuild_mfma, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
-                         cd, g_cgtab[cur_device()], TA, TE);
+      CgMix mx;
+      memset(&mx, 0, sizeof(mx));
+      if (fusedE && !smp && catmix_epilogue(w, P, k)) {  // the atom cat-mix as the kernel's epilogue (A[k + 1] zeroed by k_edge_fwd above)
+        for (int l = 0; l < 5; ++l) { mx.mf[l] = w.atom[k][l].mf; mx.ldf[l] = w.atom[k][l].ldf; mx.out[l] = w.A[k + 1][l]; }
+        mx.ldo = 2 * P.atom_cout[k]; mx.nout = P.atom_cout[k];
+        hipLaunchKernelGGL(k_catbuild_mfma<true>, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E,
+                           w.Ecm[k], w.Y, cd, g_cgtab[cur_device()], TA, TE, mx);
+        LAUNCH_CHECK();
+        continue;
+      }
+      hipLaunchKernelGGL(k_catbuild_mfma<false>, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
+                         cd, g_cgtab[cur_device()], TA, TE, mx);
     }
     LAUNCH_CHECK();
     GemmG ga[5];

@@ -58,7 +58,10 @@ def test_outputs_and_gradients_match_oracle(built_lib, canvas, width, B):
     (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
     # (7, 64): the value of a near-empty canvas is ~1e-2 and its float32 error 0.3 - 1.2e-6 absolute from seed to seed with
     # either form of the filter network (tools/dbg_int_err.py): twice the 1e-6 floor of rel_err for that case
-    tol = 2e-5 if width == 64 else 1e-5
+    # (7, 128, 140): log-prob is the sum of five head terms of magnitude 1 - 10 each; sample 93 of this batch has them cancel to
+    # 0.081, and the float32 error of the sum -- 1.15e-6 absolute, 2e-7 of the terms -- reads as 1.4e-5 of the result
+    # (tools/dbg_int_140.py: next worst sample 1.8e-6; the float32 ORACLE is off by 1e-6 on the same sample): 2e-5 as well
+    tol = 2e-5 if (width == 64 or B == 140) else 1e-5
     for k in ('logp', 'ent', 'v'):
         assert rel_err(out[k], exp[k]) < tol, (k, rel_err(out[k], exp[k]))
     got = ac.theta.grad.double().cpu()

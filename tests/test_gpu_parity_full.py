@@ -119,6 +119,25 @@ def test_weight_stationary_column_gemm_vs_oracle(built_lib):
     assert ' passed' in r.stdout and 'deselected' in r.stdout
 
 
+def test_catmix_epilogue_vs_oracle(built_lib):
+    """[r5] MG_CATMIX_EPI=1: the atom cat-mix of the levels >= 1 as the epilogue of the CG kernel (cg_mfma.inc: CgMix; partial sums of
+    the channel-waves by float atomics into representations zeroed by k_edge_fwd) instead of the row GEMM launch -- off by default
+    (measured neutral), read once per process: hence the child interpreter.  Outputs, every saved stage and every gradient of the SF6
+    mini-batch and the canvas-12 case against the oracle (the one-launch-per-level kernels of the small mini-batches carry it)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MG_CATMIX_EPI='1')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
+                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
+                        os.path.join(here, 'test_gpu_forward.py'),
+                        '-k', 'sf6_full or grads_cfg2 or encoder_stages or canvas12'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'deselected' in r.stdout
+
+
 def test_other_channel_counts_vs_oracle(built_lib):
     """num_channels_hidden = 8, num_channels_per_element = 2 (arg_parser.py:55-60 makes them command-line flags): the channel
     counts are compile-time constants of a library build, so this agent loads its own build of the same sources

@@ -11,7 +11,7 @@ steps=${3:-20}
 warm=3
 out=gpurun_out/$tag
 mkdir -p $out
-marker=k_prep_weights; if [ "$config" = "cfg2" ]; then marker=k_prep_lists; fi  # first kernel of a step (small batches: the merged launch)
+marker=k_prep_weights; if [ "$config" = "cfg2" ]; then marker=k_level0_fwd; fi  # first kernel of a step (small batches: the merged launch)
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out -o fetch_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/fetch_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out -o write_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/write_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out -o sq_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/sq_$config.log 2>&1
