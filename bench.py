@@ -160,11 +160,14 @@ def main_internal(args):
 
     every, count = max(1, args.allreduce_every), [0]
 
+    epoch_cache = os.environ.get('MG_EPOCH_CACHE', '1') != '0'
+
     def step():
         if count[0] % every == 0:  # once per epoch of `every` mini-batches (see the covariant leg)
             ac.theta.grad.zero_()
+            ac.invalidate_weights()  # the optimizer steps once per epoch: the derived weights are prepared by its first mini-batch
         count[0] += 1
-        return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+        return ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, epoch_cache=epoch_cache)
 
     for _ in range(args.warmup):
         step()

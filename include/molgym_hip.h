@@ -58,8 +58,8 @@ typedef struct mg_cov_cfg {
 const char* mg_last_error(void);
 /* MG_ABI_VERSION is bumped whenever an entry point is added / changed or the workspace layout changes; the binding
  * (molgym_amd/_lib.py::_bind) refuses a library whose mg_abi_version() differs, so a stale prebuilt .so is caught by the
- * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step; 7: mg_cov_build_params (num_cg_levels a build parameter); 8: mg_cov_ppo_step takes `flags`, mg_cov_fold_grads, derived weights first in the workspace.  */
-#define MG_ABI_VERSION 8
+ * version and not by a missing symbol.  1: rounds 1-2; 2: mg_cov_channels, mg_cov_sample_ids, channel-major workspace; 3: mg_cov_ppo_step; 4: mg_ppo_epoch_end, mg_adam_step_gated; 5: mg_cov_step_launches; 6: mg_int_ppo_step; 7: mg_cov_build_params (num_cg_levels a build parameter); 8: mg_cov_ppo_step takes `flags`, mg_cov_fold_grads, derived weights first in the workspace; 9: mg_int_ppo_step takes `flags` (MG_STEP_WEIGHTS_CURRENT), derived weights first in the SchNetAC workspace too.  */
+#define MG_ABI_VERSION 9
 int mg_abi_version(void);
 /* num_channels_hidden / num_channels_per_element THIS build of the library was compiled for (tools/arg_parser.py:55-60;
  * covariant/agent.py:64,82-83 derive every SO3Tau from them): compile-time constants of the kernels, 10 / 4 by default.
@@ -231,12 +231,15 @@ int mg_cov_ppo_step(const mg_cov_cfg* cfg, const float* theta, const float* pos,
  * (and the accumulator is left zero): the per-epoch half of what mg_cov_backward does at the end of every call.             */
 int mg_cov_fold_grads(const mg_cov_cfg* cfg, void* workspace, size_t workspace_bytes, float* grad_theta, void* stream);
 
-/* the same for the internal-coordinate agent (mg_int_forward + mg_ppo_loss + mg_int_backward) */
+/* the same for the internal-coordinate agent (mg_int_forward + mg_ppo_loss + mg_int_backward; the loss is evaluated by the last
+ * workgroup of the forward's last launch).  flags: MG_STEP_WEIGHTS_CURRENT as above (the derived weight matrices sit first in the
+ * workspace, at offsets that do not depend on the batch); this agent has no expanded gradients to fold.                       */
 int mg_int_ppo_step(const mg_int_cfg* cfg, const float* theta, const int32_t* mol_off, const int32_t* edge_off,
                     const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* workspace,
                     size_t workspace_bytes, const double* old_logp, const double* adv, const double* ret, double clip_ratio,
                     double vf_coef, double entropy_coef, double loss_scale, float* out, float* gout, double* stats,
-                    double* stats_accum, float* grad_theta, int32_t graph_slot, int32_t* used_graph_host, void* stream);
+                    double* stats_accum, float* grad_theta, int32_t graph_slot, int32_t flags, int32_t* used_graph_host,
+                    void* stream);
 
 /* kernel launches (= graph nodes) of the last mg_cov_ppo_step this host thread issued in graph form; 0 if none (measurement) */
 int mg_cov_step_launches(void);

@@ -67,7 +67,7 @@ SYMBOLS = {
     'mg_cov_fold_grads': (C.c_int, [C.POINTER(CovCfg), _P, C.c_size_t, _P, _P]),
     'mg_cov_step_launches': (C.c_int, []),
     'mg_int_ppo_step': (C.c_int, [C.POINTER(IntCfg), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, C.c_double, C.c_double,
-                                  C.c_double, C.c_double, _P, _P, _P, _P, _P, C.c_int32, C.POINTER(C.c_int32), _P]),
+                                  C.c_double, C.c_double, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P]),
     'mg_ppo_loss': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     'mg_gae': (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P]),
     'mg_adv_normalize': (C.c_int, [C.c_int32, _P, _P, _P]),
@@ -87,7 +87,7 @@ def _build_key(channels):
     return key if len(key) == 3 else key + (DEFAULT_LEVELS, )
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 STEP_WEIGHTS_CURRENT, STEP_DEFER_FOLD = 1, 2  # include/molgym_hip.h MG_STEP_*: flags of mg_cov_ppo_step  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
 
 

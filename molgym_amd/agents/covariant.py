@@ -178,6 +178,7 @@ class CovariantAC(FlatThetaAgent):
         state['_last_ws'] = None
         state.pop('_last_cfg', None)
         state.pop('_ws_cache', None)
+        state.pop('_ws_epoch', None)
         state.pop('_unchecked', None)
         state.pop('_last_out', None)
         return state

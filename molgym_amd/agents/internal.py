@@ -135,6 +135,8 @@ class SchNetAC(FlatThetaAgent):
     def __getstate__(self):  # whole-module pickling (tools/model_util.py:82-91): drop the workspace cache
         state = self.__dict__.copy()
         state['_last_ws'] = None
+        state.pop('_ws_cache', None)
+        state.pop('_ws_epoch', None)
         return state
 
     def _init_theta(self, total: int) -> torch.Tensor:
@@ -283,20 +285,49 @@ class SchNetAC(FlatThetaAgent):
         batch.logp, batch.adv, batch.ret = f64(logp), f64(adv), f64(ret)
         return batch
 
+    # ---- what depends on theta alone, once per EPOCH (ppo.py:117-146: one optimizer step per epoch), as CovariantAC does ----
+    def invalidate_weights(self) -> None:
+        """theta may have changed (start of a PPO epoch): the derived weight matrices cached in the workspaces are stale"""
+        for st in self.__dict__.get('_ws_epoch', {}).values():
+            st['weights'] = False
+
+    def fold_gradients(self) -> None:
+        """(interface of ppo.train's epoch loop: this agent has no expanded weight gradients to fold -- theta.grad is complete
+        after every mini-batch)"""
+
+    def _step_workspace(self, cfg, slot: int) -> torch.Tensor:
+        """one cached block per slot (the derived weights sit first in it, at offsets that do not depend on the batch)"""
+        nbytes = C.c_size_t()
+        _lib.check(_lib.lib().mg_int_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        cache = self.__dict__.setdefault('_ws_cache', {})
+        ws = cache.get(slot)
+        if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
+            ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
+            cache[slot] = ws
+            self.__dict__.setdefault('_ws_epoch', {}).pop(slot, None)
+        ws.record_stream(torch.cuda.current_stream(self.theta.device))
+        return ws
+
     def ppo_minibatch(self, batch: IntBatch, clip_ratio: float, vf_coef: float, entropy_coef: float,
                       loss_scale: float = 1.0, slot: int = 0, stats_accum: Optional[torch.Tensor] = None,
-                      graph: Optional[bool] = None) -> torch.Tensor:
+                      graph: Optional[bool] = None, epoch_cache: bool = False) -> torch.Tensor:
         """forward + float64 PPO loss + hand-written backward on the device (ppo.py:124-131) in ONE C call (mg_int_ppo_step),
         gradients accumulated into theta.grad (scaled by `loss_scale`: the data-parallel B_local / B_global); same signature
         and meaning as CovariantAC.ppo_minibatch: `stats_accum` receives loss_scale x statistics on the device, `graph` (default
-        on) issues the ~58 launches as one hipGraph launch whose kernel nodes are updated in place, one cached graph per `slot`.
-        Returns the 6 loss statistics (float64 device tensor, no sync)."""
+        on) issues the launches as one hipGraph launch whose kernel nodes are updated in place, one cached graph per `slot`;
+        `epoch_cache` (ppo.train's loop): the derived weight matrices of this slot's workspace are prepared by the slot's FIRST
+        mini-batch after `invalidate_weights()` only.  Returns the 6 loss statistics (float64 device tensor, no sync)."""
         lib = _lib.lib()
-        nbytes = C.c_size_t()
-        _lib.check(lib.mg_int_workspace_bytes(C.byref(batch.cfg), C.byref(nbytes)))
         B = batch.cfg.B
         dev = self.theta.device
-        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        ws = self._step_workspace(batch.cfg, slot)
+        flags = 0
+        if epoch_cache:
+            st = self.__dict__.setdefault('_ws_epoch', {}).setdefault(slot, {'weights': False})
+            flags = _lib.STEP_WEIGHTS_CURRENT if st['weights'] else 0
+            st['weights'] = True
+        else:
+            self.__dict__.get('_ws_epoch', {}).pop(slot, None)
         out = torch.empty(3, B, dtype=torch.float32, device=dev)
         stats = torch.empty(6, dtype=torch.float64, device=dev)
         gout = torch.empty(3, B, dtype=torch.float32, device=dev)
@@ -307,9 +338,9 @@ class SchNetAC(FlatThetaAgent):
         with self._guard():
             _lib.check(lib.mg_int_ppo_step(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.mol_off), _ptr(batch.edge_off),
                                            _ptr(batch.molZ), _ptr(batch.molpos), _ptr(batch.bags), _ptr(batch.actions), _ptr(ws),
-                                           nbytes.value, _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef,
+                                           ws.numel(), _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef,
                                            entropy_coef, float(loss_scale), _ptr(out), _ptr(gout), _ptr(stats), _ptr(stats_accum),
-                                           _ptr(self.theta.grad), slot if use_graph else -1, C.byref(used), self._s()))
+                                           _ptr(self.theta.grad), slot if use_graph else -1, flags, C.byref(used), self._s()))
         self._last_ws = ws
         self.last_step_used_graph = bool(used.value)
         return stats

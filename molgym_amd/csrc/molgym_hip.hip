@@ -764,15 +764,22 @@ extern "C" int mg_int_ppo_step(const mg_int_cfg* c, const float* theta, const in
                                const int32_t* molZ, const float* molpos, const float* bags, const float* actions, void* ws,
                                size_t ws_bytes, const double* old_logp, const double* adv, const double* ret, double clip_ratio,
                                double vf_coef, double entropy_coef, double loss_scale, float* out, float* gout, double* stats,
-                               double* stats_accum, float* grad_theta, int32_t graph_slot, int32_t* used_graph, void* stream) {
+                               double* stats_accum, float* grad_theta, int32_t graph_slot, int32_t flags, int32_t* used_graph,
+                               void* stream) {
   if (!c || !out || !gout || !stats || !grad_theta) MG_FAIL(MG_EINVAL, "mg_int_ppo_step: null argument");
+  if (flags & ~MG_STEP_WEIGHTS_CURRENT) MG_FAIL(MG_EINVAL, "mg_int_ppo_step: unknown flags %d", flags);
   hipStream_t s = (hipStream_t)stream;
   auto run = [&]() -> int {
-    int rc = mg_int_forward(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, out, stream);
+    static int fuse_loss = -1;
+    if (fuse_loss < 0) { const char* e = getenv("MG_FUSED_LOSS"); fuse_loss = e ? atoi(e) : 1; }
+    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum};
+    int rc = int_forward_impl(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, out, stream, fuse_loss ? &la : nullptr, flags);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
-                       entropy_coef, stats, gout, loss_scale, stats_accum);
-    LAUNCH_CHECK();
+    if (!fuse_loss) {
+      hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(256), 0, s, (int)c->B, (const float*)out, old_logp, adv, ret, clip_ratio, vf_coef,
+                         entropy_coef, stats, gout, loss_scale, stats_accum);
+      LAUNCH_CHECK();
+    }
     return mg_int_backward(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, gout, grad_theta, stream);
   };
   if (used_graph) *used_graph = 0;
@@ -784,7 +791,7 @@ extern "C" int mg_int_ppo_step(const mg_int_cfg* c, const float* theta, const in
     g_rec.end();
     if (rc) return rc;
     if (!g_rec.unsupported && !g_rec.recs.empty()) {
-      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][1][graph_slot], s);
+      hipError_t e = mg_graph_launch_recorded(g_step_graph[cur_device()][1][graph_slot + ((flags & MG_STEP_WEIGHTS_CURRENT) ? MG_GRAPH_SLOTS : 0)], s);
       if (e == hipSuccess) {
         if (used_graph) *used_graph = 1;
         return MG_OK;

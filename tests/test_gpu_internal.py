@@ -110,6 +110,36 @@ def test_graph_step_equals_stream_launches(built_lib):
         assert (res[False][1] - res[True][1]).abs().max().item() <= 2e-5 * res[False][1].abs().max().item()
 
 
+def test_epoch_cache_equals_per_minibatch_preparation(built_lib):
+    """[r5] the derived weight matrices once per EPOCH (mg_int_ppo_step flags = MG_STEP_WEIGHTS_CURRENT; they sit first in the
+    workspace, at offsets that do not depend on the batch) == every mini-batch preparing them itself: statistics bit for bit, the
+    epoch's gradient to the reproducibility of its float atomics, for mini-batches of different ragged sizes through ONE cached
+    workspace, graph and stream form, and across a change of theta (ppo.py:117-146: theta is constant over an epoch)"""
+    ac, ref = _pair(8)
+    batches = []
+    for k, B in enumerate((24, 31, 9, 140, 24)):
+        d = make_batch_internal(B, N, ZS, seed=40 + k)
+        batches.append(ac.prepare_batch(d['obs'], d['act'], d['logp'], d['adv'], d['ret']))
+    for graph in (True, False):
+        for epoch in range(2):
+            res = {}
+            for cached in (False, True):
+                ac.theta.grad = torch.zeros_like(ac.theta)
+                ac.invalidate_weights()
+                outs = [ac.ppo_minibatch(b, 0.2, 0.5, 0.01, loss_scale=0.5, graph=graph, epoch_cache=cached).clone() for b in batches]
+                if cached:
+                    assert ac._ws_epoch[0]['weights']
+                    ac.fold_gradients()
+                torch.cuda.synchronize()
+                res[cached] = (outs, ac.theta.grad.clone())
+            for s0, s1 in zip(res[False][0], res[True][0]):
+                assert torch.equal(s0, s1)
+            g0, g1 = res[False][1], res[True][1]
+            assert torch.isfinite(g1).all() and (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
+            with torch.no_grad():  # "the optimizer steps": the next epoch must see the new theta
+                ac.theta.add_(0.01 * torch.randn_like(ac.theta))
+
+
 def test_small_canvases_and_masks(built_lib):
     """n = 0, 1, 2 exercise the action masks (distance / angle / dihedral / kappa) and the null-atom focus."""
     ac, ref = _pair(3, width=64)
