@@ -246,13 +246,17 @@ class SchNetAC(FlatThetaAgent):
         index = self.action_space.zs.index(self.observation_space.zs[element])
         return index, tuple(float(x) for x in new)
 
-    def _actions_to_space(self, acts: np.ndarray, pos64: np.ndarray, natoms: np.ndarray):
+    def _actions_to_space(self, acts: np.ndarray, pos64: np.ndarray, natoms: np.ndarray, placed=None):
         """to_action_space for a whole batch of action rows: ONE vectorised z-matrix placement instead of one per sample
-        (140 single placements are 13 ms of numpy call overhead; this is 0.2 ms) -- same arithmetic, same float64 inputs."""
+        (140 single placements are 13 ms of numpy call overhead; this is 0.2 ms) -- same arithmetic, same float64 inputs.
+        `placed` = (new_plus, new_minus) of `_placements` for the same rows: the kept / flipped placement is picked, not redone."""
         a64 = np.asarray(acts, dtype=np.float32).astype(np.float64)
         focus, element = np.rint(a64[:, 1]).astype(np.int64), np.rint(a64[:, 2]).astype(np.int64)
-        sign = np.where(np.rint(a64[:, 6]) != 0, -1.0, 1.0)
-        new = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], sign * a64[:, 5])
+        if placed is not None:
+            new = np.where((np.rint(a64[:, 6]) != 0)[:, None], placed[1], placed[0])
+        else:
+            sign = np.where(np.rint(a64[:, 6]) != 0, -1.0, 1.0)
+            new = place_new_atoms(pos64, natoms, focus, a64[:, 3], a64[:, 4], sign * a64[:, 5])
         out = []
         for b in range(len(a64)):
             if a64[b, 0]:
@@ -366,8 +370,14 @@ class SchNetAC(FlatThetaAgent):
         acts[:, 4] = acts[:, 5] = 0.5 * np.pi
         nat = torch.from_numpy(natoms.astype(np.int64)).to(dev)
         with torch.no_grad():
+            # [r5] focus, element and the three continuous sub-actions only read the BASE molecules' latents (the +/- dihedral
+            # copies feed the kappa head alone), so their three passes share ONE assembled batch whose action rows are completed on
+            # the device as the draws are made; the placements are computed once all of them are known: two assemblies and uploads
+            # and one device -> host copy where there were five and four
             # focus (agent.py:206-221): softmax over the real atoms; an empty canvas focuses slot 0
-            batch = self.make_batch(observations, acts, parsed)
+            # (the first assembly's +/- copies get their new atom far outside every cutoff: nothing reads their latents yet)
+            far = 1.0e3 + 10.0 * np.arange(B, dtype=np.float64)[:, None] * np.ones((1, 3))
+            batch = self._assemble(parsed, (acts, far, far, np.full(B, self.zs[0], dtype=np.int32)))
             _, ws = self._forward_nograd(batch)
             logit_f = self._ws_view(batch.cfg, ws, 'logitF')[:batch.cfg.TA]
             dense = torch.full((B, N), float('-inf'), device=dev)
@@ -375,20 +385,19 @@ class SchNetAC(FlatThetaAgent):
             dense[slot] = logit_f
             dense[nat == 0, 0] = 0.0
             p_f = torch.softmax(dense, dim=-1)
-            focus = torch.distributions.Categorical(probs=p_f).sample() if self.training else torch.argmax(p_f, -1)
-            acts[:, 1] = focus.cpu().numpy()
+            # (torch.multinomial / torch.normal directly: what Categorical.sample / Normal.sample call, same draws from the same RNG stream)
+            focus = torch.multinomial(p_f / p_f.sum(-1, keepdim=True), 1, True).squeeze(1) if self.training else torch.argmax(p_f, -1)
+            batch.actions[:, 1] = focus.to(torch.float32)
             # element (agent.py:229-242): softmax over the elements left in the bag
-            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             logit_e = self._ws_view(batch.cfg, ws, 'logitE')[:B * Z].view(B, Z)
             mask_e = torch.from_numpy(bags > 0).to(dev)
             dense = torch.where(mask_e, logit_e, torch.full_like(logit_e, float('-inf')))
             dense[~mask_e.any(dim=-1), 0] = 0.0  # an exhausted bag never reaches the agent; keep the draw defined
             p_e = torch.softmax(dense, dim=-1)
-            element = torch.distributions.Categorical(probs=p_e).sample() if self.training else torch.argmax(p_e, -1)
-            acts[:, 2] = element.cpu().numpy()
+            element = torch.multinomial(p_e / p_e.sum(-1, keepdim=True), 1, True).squeeze(1) if self.training else torch.argmax(p_e, -1)
+            batch.actions[:, 2] = element.to(torch.float32)
             # distance / angle / dihedral (agent.py:246-292): Normal around tanh(mean) * width / 2 + center
-            batch = self.make_batch(observations, acts, parsed)
             _, ws = self._forward_nograd(batch)
             cout = self._ws_view(batch.cfg, ws, 'cout')[:B * 3].view(B, 3)
             half_w = torch.tensor([0.5 * (self.max_distance - self.min_distance), 0.5 * np.pi, 0.5 * np.pi], device=dev)
@@ -397,21 +406,23 @@ class SchNetAC(FlatThetaAgent):
             if self.training:
                 o, shp = self.slot_table['log_stds']
                 scale = torch.exp(1e-6 + self.theta[o:o + 3])
-                cont = torch.distributions.Normal(loc=mean, scale=scale).sample()
+                cont = torch.normal(mean, scale.expand_as(mean))
                 cont[:, 0].clamp_(min=0.001)  # the sampled distance must stay positive (agent.py:254-255)
             else:
                 cont = mean
-            acts[:, 3:6] = cont.cpu().numpy()
+            drawn = torch.cat([focus.to(torch.float32)[:, None], element.to(torch.float32)[:, None], cont.to(torch.float32)], dim=1)
+            acts[:, 1:6] = drawn.cpu().numpy()
             # kappa (agent.py:294-315): keep / flip the dihedral, logits from the two hypothetical placements
-            batch = self.make_batch(observations, acts, parsed)
+            placed = self._placements(parsed, acts)
+            batch = self._assemble(parsed, placed)
             _, ws = self._forward_nograd(batch)
             kv = self._ws_view(batch.cfg, ws, 'kv')[:2 * B].view(2, B).t()
-            kappa = torch.distributions.Categorical(logits=kv).sample() if self.training else torch.argmax(kv, -1)
+            kappa = torch.multinomial(torch.softmax(kv, dim=-1), 1, True).squeeze(1) if self.training else torch.argmax(kv, -1)
+            batch.actions[:, 6] = kappa.to(torch.float32)
+            out, _ = self._forward_nograd(batch)  # the plain evaluation of the completed rows
             acts[:, 6] = kappa.cpu().numpy()
-            batch = self.make_batch(observations, acts, parsed)
-            out, _ = self._forward_nograd(batch)
         return {'a': batch.actions, 'logp': out[0], 'ent': out[1], 'v': out[2],
-                'actions': self._actions_to_space(acts, pos64, natoms)}
+                'actions': self._actions_to_space(acts, pos64, natoms, placed[1:3])}
 
     def step(self, observations: List[ObservationType], actions: Optional[np.ndarray] = None) -> Dict[str, Any]:
         if self.theta.device.type != 'cuda':
