@@ -152,8 +152,9 @@ class CovariantAC(FlatThetaAgent):
         self.beta = beta
         self.max_sh, self.num_cg_levels = maxl, num_cg_levels
         self.num_channels_hidden, self.num_channels_per_element = num_channels_hidden, num_channels_per_element
-        if network_width > 128 or network_width % 4:
-            raise RuntimeError(f'network_width {network_width}: the HIP heads kernels support multiples of 4 up to 128')
+        if network_width > 1024 or network_width % 4:
+            # (<= 128: all heads in one launch per direction; wider: the staged head kernels + row GEMMs, any multiple of 4)
+            raise RuntimeError(f'network_width {network_width}: the HIP heads kernels support multiples of 4 up to 1024')
         self.num_gaussians, self.network_width, self.bag_scale = num_gaussians, network_width, bag_scale
         self.num_channels_out = len(self.zs) * num_channels_per_element
         self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)  # (C, Ce, levels)

@@ -496,7 +496,7 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
   APtrs A3;
   for (int l = 0; l < 5; ++l) A3.p[l] = w.A[NLEV][l];
   A3.C = Co;
-  if (!smp && !use_staged_heads()) {  // action evaluation: all heads in one launch (heads_fused.inc)
+  if (!smp && !use_staged_heads(c->W)) {  // action evaluation: all heads in one launch (heads_fused.inc)
     HeadDims HD;
     HeadW HW;
     HeadBuf HB;

@@ -169,6 +169,37 @@ def test_other_channel_counts_vs_oracle(built_lib):
     assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
 
 
+def test_network_width_256_vs_oracle(built_lib):
+    """[r5] --network_width above 128 (a flag upstream, arg_parser.py:57; every BASELINE config uses 128): the heads run as the
+    staged kernels + row GEMMs of any width (heads_fused.inc::use_staged_heads) instead of the one-launch-per-direction form --
+    outputs and every parameter gradient against the oracle built with the same width, and the one-call PPO step against autograd"""
+    ac, ref, cfg = make_pair('cfg2', seed=23, network_width=256)
+    data = make_batch(24, cfg['canvas_size'], cfg['zs'], seed=37)
+    B = len(data['obs'])
+    g = torch.Generator().manual_seed(4)
+    wl, we, wv = (torch.randn(B, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
+    out = ac.step(data['obs'], data['act'])
+    (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
+    assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), dict(ref.named_parameters()), ac.slot_table))
+    # the PPO mini-batch call (forward, float64 loss, backward in one call) == loss.backward() through the autograd node
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    ac.theta.grad = torch.zeros_like(ac.theta)
+    ac.ppo_minibatch(batch, 0.2, 0.5, 0.01)
+    torch.cuda.synchronize()
+    g_dev = ac.theta.grad.clone()
+    ac.theta.grad = None
+    from molgym_amd import ppo as hip_ppo
+    loss, _ = hip_ppo.compute_loss(ac, data, 0.2, 0.5, 0.01)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (g_dev - ac.theta.grad).abs().max().item() <= 2e-4 * ac.theta.grad.abs().max().item()
+
+
 @pytest.mark.parametrize('levels', [2, 4])
 def test_other_num_cg_levels_vs_oracle(built_lib, levels):
     """num_cg_levels = 2 / 4 (arg_parser.py:56 makes it a command-line flag; 3 is the default): a build parameter of the
