@@ -11,7 +11,7 @@ steps=${3:-20}
 warm=3
 out=gpurun_out/$tag
 mkdir -p $out
-marker=k_prep_weights; if [ "$config" = "cfg2" ]; then marker=k_level0_fwd; fi  # first kernel of a step (small batches: the merged launch)
+marker=k_prep_weights; if [ "$config" = "cfg2" ]; then marker="void k_level0_fwd"; fi  # first kernel of a step (small batches: the merged launch)
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out -o fetch_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/fetch_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out -o write_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/write_$config.log 2>&1
 timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out -o sq_$config -- python bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-epoch-overlap > $out/sq_$config.log 2>&1
@@ -25,5 +25,5 @@ timeout -k 5 300 rocprofv3 --kernel-trace -d $out -o prof_$config -- python benc
 # launches in the trace: warm-up + timed steps + the 20 iterations of the live roofline leg
 python tools/rocpd_summary.py $out/prof_${config}_results.db $out/kernel_stats_$config.csv $((steps + warm + 20)) > /dev/null && head -14 $out/kernel_stats_$config.csv && tail -1 $out/kernel_stats_$config.csv
 # a TIMED step (the trace ends with the 20 event-bracketed steps of the live roofline leg)
-python tools/rocpd_timeline.py $out/prof_${config}_results.db $marker 22 > $out/timeline_$config.txt 2>&1
+python tools/rocpd_timeline.py $out/prof_${config}_results.db "$marker" 22 > $out/timeline_$config.txt 2>&1
 rm -f $out/*_results.db

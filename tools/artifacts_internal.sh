@@ -10,5 +10,5 @@ BENCH_WATCHDOG=300 timeout -k 5 400 python bench.py --agent internal --steps 50 
 tail -1 $out/bench_internal.json | cut -c1-1500
 timeout -k 5 300 rocprofv3 --kernel-trace -d $out -o prof_internal -- python bench.py --agent internal --steps $steps --warmup 3 --no-cpu-baseline --no-build > $out/bench_prof_internal.log 2>&1
 python tools/rocpd_summary.py $out/prof_internal_results.db $out/kernel_stats_internal.csv $((steps + 3)) > /dev/null && head -24 $out/kernel_stats_internal.csv && tail -1 $out/kernel_stats_internal.csv
-python tools/rocpd_timeline.py $out/prof_internal_results.db k_prep_weights > $out/timeline_internal.txt 2>&1
+python tools/rocpd_timeline.py $out/prof_internal_results.db k_int_fill_lists > $out/timeline_internal.txt 2>&1
 rm -f $out/*_results.db
