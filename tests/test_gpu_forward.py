@@ -201,6 +201,11 @@ def test_unsupported_width_is_rejected(built_lib):
     from molgym_amd.spaces import ActionSpace, ObservationSpace
     from molgym_amd.synthetic import MODEL_DEFAULTS
     md = dict(MODEL_DEFAULTS)
-    md['network_width'] = 256
+    # (256 is supported since round 5 -- the staged heads, tests/test_gpu_parity_full.py::test_network_width_256_vs_oracle; what is
+    # rejected: widths that are not a multiple of 4, and widths above 1024)
+    md['network_width'] = 130
+    with pytest.raises(RuntimeError):
+        CovariantAC(ObservationSpace(7, [0, 9, 16]), ActionSpace([0, 9, 16]), bag_scale=5, beta=-10.0, device='cuda:0', **md)
+    md['network_width'] = 2048
     with pytest.raises(RuntimeError):
         CovariantAC(ObservationSpace(7, [0, 9, 16]), ActionSpace([0, 9, 16]), bag_scale=5, beta=-10.0, device='cuda:0', **md)
