@@ -119,6 +119,26 @@ def test_weight_stationary_column_gemm_vs_oracle(built_lib):
     assert ' passed' in r.stdout and 'deselected' in r.stdout
 
 
+def test_round5_forced_large_batch_kernels_vs_oracle(built_lib):
+    """[r5] Two kernels that only run at row / edge counts the oracle does not reach in seconds, forced on the small oracle cases in
+    ONE child interpreter (their switches are read once per process): the LDS-stationary-weights row GEMM of the atom cat-mixes
+    (gemm.inc: k_gemm_mfma_rows_ws; MG_ROWS_WS_MIN=1, MG_ROWS_WS=2 also takes the 40-wide last-level mixes of Z = 5 that leave room
+    for one 8-wave workgroup per CU) and the opt-in molecule-stationary CG adjoint (backward.inc: k_catbuild_bwd_mol; MG_CGB_MOL=0 =
+    from zero edges).  Outputs and every parameter gradient against the oracle (the masked full-size comparison of
+    tests/test_gpu_large.py runs rows_ws at its real sizes)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MG_ROWS_WS_MIN='1', MG_ROWS_WS='2', MG_CGB_MOL='0')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
+                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
+                        '-k', 'canvas20_crowded or canvas40_crowded or sf6_full or grads_five'],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'deselected' in r.stdout
+
+
 def test_catmix_epilogue_vs_oracle(built_lib):
     """[r5] MG_CATMIX_EPI=1: the atom cat-mix of the levels >= 1 as the epilogue of the CG kernel (cg_mfma.inc: CgMix; partial sums of
     the channel-waves by float atomics into representations zeroed by k_edge_fwd) instead of the row GEMM launch -- off by default
