@@ -356,18 +356,40 @@ def main():
         # evidence for the scaling record: how many RCCL ranks there were, which device each drove, and that after the last
         # all-reduce of the timed region every replica holds the SAME gradient (bit for bit: RCCL's ring sum is the same
         # sequence of additions on every rank)
-        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=dev))
+        devs = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        props = torch.cuda.get_device_properties(dev)
+        # (the physical identity too: a launcher that narrows the visible devices per rank makes every rank's index 0)
+        phys = (int(getattr(props, 'pci_domain_id', 0)) << 16) | (int(getattr(props, 'pci_bus_id', -1)) << 8) | int(getattr(props, 'pci_device_id', 0))
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device(), phys], dtype=torch.int64, device=dev))
         g = ac.theta.grad
         probe = torch.stack([g.double().sum(), g.double().abs().sum(), g[::997].double().pow(2).sum()])
         lo, hi = probe.clone(), probe.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist_info = {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
-                     'rank_devices': [int(d.item()) for d in devs],
+                     'rank_devices': [int(d[0].item()) for d in devs],
+                     'rank_pci': [int(d[1].item()) for d in devs],
                      'replicas_equal': bool(torch.equal(lo, hi)) and bool(torch.isfinite(probe).all()),
                      'grad_abs_sum': float(probe[1].item()),
                      'allreduces_in_timed_region': n_allreduce[0] - n_allreduce_warm[0]}
+        # the 8-GPU run must fail loudly or pass, never quietly degrade (a rank that fell back to another device, a process
+        # group of the wrong size, replicas that drifted apart): checked on every rank, non-zero exit
+        problems = []
+        if dist_info['rccl_ranks'] != args.gpus:
+            problems.append(f"process group has {dist_info['rccl_ranks']} ranks, --gpus {args.gpus}")
+        if dist_info['backend'] != 'nccl':
+            problems.append(f"backend {dist_info['backend']} is not RCCL")
+        if len(set(dist_info['rank_pci'])) != world and len(set(dist_info['rank_devices'])) != world:
+            problems.append(f"ranks share devices: {dist_info['rank_devices']} / pci {dist_info['rank_pci']}")
+        if not dist_info['replicas_equal']:
+            problems.append('replicas hold different gradients after the last all-reduce')
+        if dist_info['allreduces_in_timed_region'] < 1:
+            problems.append('no gradient all-reduce inside the timed region')
+        if problems:
+            if rank == 0:
+                print(json.dumps({'error': 'multi-GPU check failed', 'problems': problems, 'dist': dist_info}))
+            dist.destroy_process_group()
+            raise SystemExit(3)
     # Second leg (one GPU, default run only): the same K mini-batch steps with three in flight on separate HIP streams, the
     # way ppo.train issues the mini-batches of ONE epoch -- the reference zeroes the gradient once per epoch and lets the
     # mini-batches accumulate into it (molgym/ppo.py:117-131), so they are independent given theta.  Reported beside the
@@ -428,6 +450,48 @@ def main():
     if streams is None:
         median_ms = float(np.median([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]))
 
+    # Fourth / fifth legs (one GPU, default run): (a) the SAME step on the schedule of the reference's README command for SF6
+    # (/root/reference/README.md:79-80: --num_steps_per_iter=140 --mini_batch_size=140 => ONE mini-batch per epoch, theta changes
+    # after every mini-batch): gradient zero, derived-weight preparation and the fold of the expanded weight gradients on EVERY
+    # step, nothing amortised; (b) a long run of the headline's schedule (>= 2000 steps where the step is short), mean and median,
+    # so that the driver's 20-step sample can be cross-read.
+    def timed_leg(k, cadence):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+        for i in range(min(10, k)):  # (re-warm: the graph execs of this cadence)
+            one_step(i, cadence, i == min(10, k) - 1)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ev[0].record()
+        for i in range(k):
+            st_ = one_step(i, cadence, i == k - 1)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if not torch.isfinite(st_).all():
+            raise SystemExit('non-finite loss statistics (extra leg)')
+        per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(k)])
+        return {'steps': k, 'value': total_samples * k / dt, 'unit': 'samples/s', 'ms_per_step': dt / k * 1e3,
+                'median_ms_per_step': float(np.median(per)), 'p10_ms': float(np.percentile(per, 10)),
+                'p90_ms': float(np.percentile(per, 90)), 'timed_region_ms': dt * 1e3}
+
+    def one_step(i, cadence, last):
+        if i % cadence == 0:
+            ac.theta.grad.zero_()
+            ac.invalidate_weights()
+        out_ = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=loss_scale, epoch_cache=epoch_cache)
+        if (i + 1) % cadence == 0 or last:
+            ac.fold_gradients()
+        return out_
+
+    cadence1_leg = long_leg = None
+    if streams is None and not use_dist and world == 1 and not args.no_epoch_overlap:
+        ms_now = elapsed / args.steps * 1e3
+        cadence1_leg = timed_leg(max(args.steps, min(200, int(200.0 / ms_now) + 1)), 1)
+        cadence1_leg['note'] = ('every step is an epoch (the reference README SF6 command: one 140-sample mini-batch per epoch): '
+                                'gradient zero + derived weights + weight-gradient fold on EVERY step')
+        long_leg = timed_leg(max(args.steps, min(2000, int(1500.0 / ms_now) + 1)), every)
+        long_leg['note'] = f"the headline's schedule (zero / derived weights / fold every {every} steps), long sample"
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed
@@ -479,7 +543,11 @@ def main():
             'roofline': roof,
             'epoch_overlap': epoch_leg,
             'with_host_parse': parse_leg,
+            'every_step_is_an_epoch': cadence1_leg,
+            'long_run': long_leg,
         }
+        line['config']['value_every_step_is_an_epoch'] = None if cadence1_leg is None else cadence1_leg['value']
+        line['config']['value_long_run'] = None if long_leg is None else long_leg['value']
         from molgym_amd.profile import step_hbm
         line['config'].update(step_hbm(args.config, ms))
         if not args.no_cpu_baseline and world == 1:

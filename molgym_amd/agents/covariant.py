@@ -303,11 +303,14 @@ class CovariantAC(FlatThetaAgent):
         self._chk(self._L().mg_cov_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         cache = self.__dict__.setdefault('_ws_cache', {})
         ws = cache.get(slot)
+        # Only THIS slot is folded here, on the current stream = the stream this slot's mini-batches were issued on
+        # (ppo._DeviceRunner.run): the other slots' backward launches may still be adding to their accumulators on their own
+        # streams, and k_fold_weights reads-then-zeroes non-atomically -- folding them from here would lose what lands in between.
         if not epoch_step and self.__dict__.get('_ws_epoch', {}).get(slot, {}).get('pending'):
-            self.fold_gradients()  # another kind of call on a workspace that still holds an epoch's deferred weight gradients
+            self.fold_gradients(slot)  # another kind of call on a workspace that still holds an epoch's deferred weight gradients
         if ws is None or ws.numel() < nbytes.value or ws.device != self.theta.device:
             if self.__dict__.get('_ws_epoch', {}).get(slot, {}).get('pending'):
-                self.fold_gradients()  # (the block is about to be replaced)
+                self.fold_gradients(slot)  # (the block is about to be replaced)
             ws = torch.empty(int(nbytes.value * 1.25), dtype=torch.uint8, device=self.theta.device)
             cache[slot] = ws
             self.__dict__.setdefault('_ws_epoch', {}).pop(slot, None)
@@ -321,14 +324,24 @@ class CovariantAC(FlatThetaAgent):
         """theta may have changed (start of a PPO epoch): the derived weight matrices cached in the workspaces are stale"""
         for st in self.__dict__.get('_ws_epoch', {}).values():
             st['weights'] = False
+            # A slot still pending HERE was left by an epoch that never reached its fold (an exception between its mini-batches
+            # and end_epoch): what its accumulator holds belongs to a gradient that was abandoned.  Drop the claim -- the slot's
+            # next epoch_cache step prepares the weights anew, which zeroes the accumulator; a slot the new epoch never touches is
+            # then NOT folded into the new theta.grad by end_epoch.
+            st['pending'] = False
 
-    def fold_gradients(self) -> None:
-        """mg_cov_fold_grads for every workspace whose mini-batches ran with `epoch_cache=True` since the last fold: theta.grad is
-        complete only after this (ppo.train calls it once per epoch, before the all-reduce / norm / clip / Adam step).  Issued on
-        the current stream, which must already be ordered behind the mini-batches' streams (ppo._DeviceRunner.end_epoch)."""
-        for slot, st in self.__dict__.get('_ws_epoch', {}).items():
+    def fold_gradients(self, slot: Optional[int] = None) -> None:
+        """mg_cov_fold_grads for every workspace (`slot=None`) -- or the one of `slot` -- whose mini-batches ran with
+        `epoch_cache=True` since the last fold: theta.grad is complete only after the all-slot call (ppo.train: once per epoch,
+        before the all-reduce / norm / clip / Adam step).  Issued on the current stream, which must already be ordered behind
+        the streams of the slots it folds (all of them: ppo._DeviceRunner.end_epoch after its wait_stream joins; one: the
+        slot's own stream, _workspace)."""
+        for sl, st in self.__dict__.get('_ws_epoch', {}).items():
+            if slot is not None and sl != slot:
+                continue
+            slot_ = sl
             if st.get('pending'):
-                ws = self._ws_cache[slot]
+                ws = self._ws_cache[slot_]
                 with self._guard():
                     self._chk(self._L().mg_cov_fold_grads(C.byref(st['cfg']), _ptr(ws), ws.numel(), _ptr(self.theta.grad), self._s()))
                 ws.record_stream(torch.cuda.current_stream(self.theta.device))

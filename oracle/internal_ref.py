@@ -76,6 +76,31 @@ class SchNet(nn.Module):
         return x
 
 
+# ---- z-matrix internal coordinates (internal/zmat.py:6-63), float64 numpy ------------------------------------
+def get_distance(p_i, p_j):
+    """zmat.py:6-14 (also the sort key of the placement, zmat.py:113)"""
+    return np.sqrt(np.sum(np.square(p_i - p_j)))
+
+
+def get_angle(p_i, p_j, p_k):
+    """zmat.py:17-31: angle at j, from |a x b| and a . b"""
+    a, b = p_i - p_j, p_k - p_j
+    return np.arctan2(np.linalg.norm(np.cross(a, b)), np.dot(a, b))
+
+
+def get_dihedral(p_i, p_j, p_k, p_l):
+    """zmat.py:34-63: signed dihedral i-j-k-l in (-pi, pi]; NaN for collinear points (the normals have zero length), as the
+    reference's test_dihedral_nan expects"""
+    b0, b1, b2 = p_j - p_i, p_k - p_j, p_l - p_k
+    n1 = np.cross(b0, b1)
+    n1 = n1 / np.linalg.norm(n1)
+    n2 = np.cross(b2, b1)
+    n2 = n2 / np.linalg.norm(n2)
+    m1 = np.cross(n1, b1) / np.linalg.norm(b1)
+    psi = np.arctan2(np.dot(m1, n2), np.dot(n1, n2))
+    return -psi - np.pi if psi < 0 else np.pi - psi
+
+
 # ---- z-matrix placement (internal/zmat.py:66-133), float64 numpy --------------------------------------------
 def position_point(p0, p1, p2, distance, angle, dihedral):
     x = distance * np.cos(angle)

@@ -35,6 +35,12 @@ def loss_from_pred(logp, ent, v, old_logp, adv, ret, clip_ratio, vf_coef, entrop
     return loss, info
 
 
+def gradient_norm_ref(parameters):
+    """tools/util.py:61-69: 2-norm of the per-tensor gradient 2-norms (0.0 without any gradient)."""
+    norms = [p.grad.detach().norm(2) for p in parameters if p.grad is not None]
+    return torch.stack(norms).norm(2).item() if norms else 0.0
+
+
 def discount_cumsum_ref(x, discount):
     out = np.zeros_like(np.asarray(x, dtype=np.float64))
     run = 0.0

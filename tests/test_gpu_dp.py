@@ -43,3 +43,31 @@ def test_bench_rccl_path_forced_at_world_1(built_lib):
     assert d['replicas_equal'] is True and d['allreduces_in_timed_region'] == 2  # 20 steps, one all-reduce per 10
     assert line['n_gpus'] == 1 and line['steps'] == 20 and line['value'] > 0 and line['config']['allreduce_every_steps'] == 10
     assert line['config']['issued_as_one_graph_launch'] is True
+
+
+def test_bench_rccl_path_forced_at_world_1_strong_scaling(built_lib):
+    """the `--scaling strong` form of the same run (whole mini-batches dealt round-robin like ppo.shard_epoch; K rounded up
+    to a multiple of world x allreduce_every): what a fixed-rollout 8-GPU run executes."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--scaling', 'strong', '--steps', '20',
+           '--warmup', '5', '--no-cpu-baseline', '--no-epoch-overlap', '--no-build']
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    d = line['dist']
+    assert line['scaling'] == 'strong' and d['rccl_ranks'] == 1 and d['replicas_equal'] is True
+    assert d['allreduces_in_timed_region'] == 2 and line['steps'] == 20 and line['value'] > 0
+
+
+def test_bench_line_of_the_internal_agent(built_lib):
+    """BASELINE configs[0] (SchNetAC, SF6, canvas 7, mini-batch 140): `bench.py --agent internal` produces a line with the
+    `roofline` and `cpu_baseline` objects (a short CPU leg), so the driver's GPU record proves that measurement path."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--agent', 'internal', '--steps', '20', '--warmup', '5', '--no-build',
+           '--cpu-seconds', '3']
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert 'internal' in line['metric'] and line['value'] > 0 and line['steps'] == 20
+    assert line['roofline'] and line['roofline'].get('frac') is not None
+    assert line['cpu_baseline'] and line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['kind'] == 'port'

@@ -42,6 +42,22 @@ def test_vectorised_zmat_matches_scalar_helper(built_lib):
         np.testing.assert_allclose(got[b], want, rtol=1e-12, atol=1e-12)
 
 
+def test_product_placement_against_the_reference_vectors(built_lib):
+    """G8 (tests/golden/g8_zmat.npz: zmat.position_atom_helper of the reference for 0 / 1 / 2 / 3 / 5 atoms, written by
+    oracle/make_golden.py): the product's vectorised placement, all five cases in ONE call, exact -- and through the agent's own
+    action conversion (SchNetAC.to_action_space), which is what the rollout hands to the environment."""
+    import os
+    from molgym_amd.agents.internal import place_new_atoms
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g8_zmat.npz'))
+    ns = (0, 1, 2, 3, 5)
+    pos = np.zeros((len(ns), N, 3))
+    args = np.stack([g[f'n{n}_args'] for n in ns])
+    for r, n in enumerate(ns):
+        pos[r, :n] = g[f'n{n}_pos']
+    got = place_new_atoms(pos, np.array(ns), args[:, 0].astype(np.int64), args[:, 1], args[:, 2], args[:, 3])
+    np.testing.assert_array_equal(got, np.stack([g[f'n{n}_out'] for n in ns]))
+
+
 @pytest.mark.parametrize('canvas,width,B', [(7, 128, 24), (12, 128, 24), (20, 128, 24), (7, 64, 24), (7, 128, 140)])
 def test_outputs_and_gradients_match_oracle(built_lib, canvas, width, B):
     """(7, 128) and (12, 128): the SchNet interactions as one launch per direction, 8- and 16-atom layouts (schnet_fused.inc);

@@ -61,6 +61,20 @@ def test_grad_norm_and_clip(built_lib):
         assert torch.allclose(gdev.cpu(), p.grad, rtol=1e-5, atol=1e-7)
 
 
+def test_grad_norm_kernel_against_the_reference_value(built_lib):
+    """G9: util.compute_gradient_norm of the reference (tools/util.py:61-69) on the gradients of G4's MLP, stored by
+    oracle/make_golden.py as g4['grad_norm']; mg_grad_norm_clip reports the same norm from the flat gradient."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g4_mlp.npz'))
+    flat = torch.cat([torch.tensor(g[k]).reshape(-1) for k in g.files if k.startswith('grad_') and k != 'grad_norm']).cuda()
+    keep = flat.clone()
+    out = torch.zeros(2, device='cuda')
+    _lib.check(built_lib.mg_grad_norm_clip(flat.numel(), P(flat), 1e9, P(out), S()))
+    want = float(g['grad_norm'])
+    assert abs(out[0].item() - want) <= 1e-6 * want
+    assert torch.equal(flat, keep)  # far below the limit: untouched
+
+
 def test_fused_minibatch_equals_autograd_path(built_lib):
     """ppo_minibatch (device loss + hand-written backward) == compute_loss through autograd == oracle."""
     from molgym_amd import ppo

@@ -68,6 +68,13 @@ def test_g4_mlp_and_one_hot():
     for k, p in mlp.named_parameters():
         np.testing.assert_allclose(p.grad.numpy(), g[f'grad_{k}'], rtol=1e-5, atol=1e-6)
     np.testing.assert_array_equal(to_one_hot(torch.tensor(g['oh_idx']), 4).numpy(), g['oh'])
+    # G9: util.compute_gradient_norm (tools/util.py:61-69) of the same gradients -- the oracle's restatement (norm of the
+    # per-tensor norms) and the product's host mirror (molgym_amd/ppo.py::compute_gradient_norm) against the reference's value
+    from oracle.ppo_ref import gradient_norm_ref
+    want = float(g['grad_norm'])
+    assert abs(gradient_norm_ref(mlp.parameters()) - want) <= 1e-6 * want
+    from molgym_amd.ppo import compute_gradient_norm
+    assert abs(compute_gradient_norm(mlp.parameters()) - want) <= 1e-6 * want
     try:
         to_one_hot(torch.tensor([[5]]), 4)  # tests/test_modules.py:22-29
         raise AssertionError('out-of-range index must raise')
@@ -123,6 +130,48 @@ def test_g7_spherical_distributions():
     np.testing.assert_allclose(d1.log_prob(dirs).numpy(), g['so3_logp'], rtol=1e-4, atol=1e-4)
     pts, w = lebedev_71()
     assert pts.shape == (1730, 3) and abs(w.sum() - 1) < 1e-12
+
+
+def test_g8_zmat_placement_and_internal_coordinates():
+    """internal/zmat.py:66-133 of the reference (position_atom_helper for 0 / 1 / 2 / 3 / 5 atoms, get_distance / get_angle /
+    get_dihedral): the oracle's scalar restatement AND the product's vectorised host placement, exact (float64 numpy on both
+    sides, same operation order)."""
+    from oracle.internal_ref import get_angle, get_dihedral, get_distance, position_atom
+    from molgym_amd.agents.internal import place_new_atoms
+    g = load('g8_zmat.npz')
+    for n in (0, 1, 2, 3, 5):
+        pos, (focus, d, ang, dih) = g[f'n{n}_pos'], g[f'n{n}_args']
+        want = g[f'n{n}_out']
+        got = position_atom([pos[i] for i in range(n)], int(focus), d, ang, dih)
+        np.testing.assert_array_equal(got, want)
+        padded = np.zeros((1, 7, 3))
+        padded[0, :n] = pos
+        prod = place_new_atoms(padded, np.array([n]), np.array([int(focus)]), np.array([d]), np.array([ang]), np.array([dih]))
+        np.testing.assert_array_equal(prod[0], want)
+    p = g['geo_pts']
+    np.testing.assert_array_equal(
+        np.array([get_distance(p[0], p[1]), get_angle(p[0], p[1], p[2]), get_dihedral(p[0], p[1], p[2], p[3])]), g['geo'])
+
+
+def test_zmat_known_answers_of_the_reference_tests():
+    """tests/agents/internal/test_zmat.py:10-72 of the reference, as literal known answers."""
+    from oracle.internal_ref import get_angle, get_dihedral, get_distance, position_point
+    e = np.eye(3)
+    o = np.zeros(3)
+    assert get_distance(o, o) == 0 and get_distance(o, e[0]) == 1 and abs(get_distance(e[0], e[1]) - math.sqrt(2)) < 1e-12
+    assert abs(get_angle(e[0], o, e[0])) < 1e-12 and abs(get_angle(e[0], o, e[1]) - math.pi / 2) < 1e-12
+    assert abs(get_angle(e[0], o, -e[0]) - math.pi) < 1e-12
+    p1, p2, p3 = np.array([0, 0, 1.5]), o, np.array([0, 0.5, 0])
+    for psi in np.arange(-math.pi + 1e-4, math.pi - 1e-4, math.pi / 17):
+        assert abs(get_dihedral(p1, p2, p3, np.array([math.sin(psi), 0.5, math.cos(psi)])) - psi) < 1e-7
+    assert get_dihedral(e[2], o, e[1], e[0]) == math.pi / 2 and get_dihedral(e[2], o, e[1], -e[0]) == -math.pi / 2
+    with np.errstate(invalid='ignore'):
+        line = [np.array([x, 0.0, 1.0]) for x in (0.5995394918, -0.5995394918, -1.6616385861, 1.6616385861)]
+        assert np.isnan(get_dihedral(*line))
+    # a placed point reproduces the internal coordinates it was placed with
+    q = position_point(e[2], o, e[1], 1.3, 1.9, -0.7)
+    assert abs(get_distance(q, e[1]) - 1.3) < 1e-12 and abs(get_angle(q, e[1], o) - 1.9) < 1e-12
+    assert abs(get_dihedral(q, e[1], o, e[2]) + 0.7) < 1e-12
 
 
 def test_known_answers_of_the_reference_tests():
