@@ -44,7 +44,7 @@ def deconflict(ents, gm, to_dw, seed):
         return [to_dw(ents[t][assign[t][j]][0]) if t < n and assign[t][j] is not None else None for t in range(64)]
     cost = [_slot_cycles(offs(j)) for j in range(gm)]
     if gm > 1:
-        for _ in range(4000 * gm):
+        for _ in range(10000 * gm):
             t = rng.randrange(n)
             j1, j2 = rng.sample(range(gm), 2)
             if assign[t][j1] is None and assign[t][j2] is None:
@@ -71,6 +71,85 @@ def deconflict(ents, gm, to_dw, seed):
                     row[t] = (real[0] if real else 0, 0.0)
         slots.append(row)
     return slots
+
+
+def _write_cycles(addrs):
+    """LDS array cycles of one 8-byte store instruction (ds_write_b64): four groups of 16 CONTIGUOUS lanes, bank = dword address
+    mod 32, a lane covers two banks; identical addresses count once (addrs: 64 dword addresses)"""
+    tot = 0
+    for g in range(4):
+        banks = {}
+        for a in addrs[16 * g:16 * g + 16]:
+            banks.setdefault(a % 32, set()).add(a)
+            banks.setdefault((a + 1) % 32, set()).add(a)
+        tot += max(len(v) for v in banks.values())
+    return tot
+
+
+def order_for_stores(items, counts, gmax, addr_fns, pad_addr, seed, iters=60000):
+    """A lane of a 64-lane group stores its result(s) at addresses the data layout dictates; WHICH lane of WHICH group takes which
+    item is free as long as the item's term count fits the group's slot count gmax[g].  items (in the sorted work order: feasible)
+    -> list of groups of 64 (None = padding lane, stores at pad_addr) such that every group's store instructions (one per function
+    in addr_fns: item -> dword address of an 8-byte store) hit as few common banks per 16-lane store group as a local search over
+    pairwise exchanges finds.  Round 6: the stores of the rebuilt adjoint moments / of the projected rows cost 3.5x / 2.4x their
+    conflict-free cycles in the sorted order (tools/lds_model.py)."""
+    import random
+    rng = random.Random(seed)
+    ng = len(gmax)
+    slots = list(items) + [None] * (64 * ng - len(items))
+    cnt = lambda x: 0 if x is None else counts[x]  # noqa: E731
+
+    def gcost(g):
+        # search objective: the number of EXTRA distinct addresses per bank, summed over the group's 16-lane store groups and
+        # stores (0 = conflict-free; the cycle count itself, a maximum per store group, is flat almost everywhere)
+        tot = 0
+        for f in addr_fns:
+            for sg in range(4):
+                banks = {}
+                for x in slots[64 * g + 16 * sg:64 * g + 16 * sg + 16]:
+                    a = f(x) if x is not None else pad_addr
+                    banks.setdefault(a % 32, set()).add(a)
+                    banks.setdefault((a + 1) % 32, set()).add(a)
+                tot += sum(len(v) - 1 for v in banks.values())
+        return tot
+    def sub_bad(sg):
+        """lanes of 16-lane store group sg that sit on a bank another lane of the group uses too (for any of the stores)"""
+        bad = set()
+        for f in addr_fns:
+            banks = {}
+            for t in range(16 * sg, 16 * sg + 16):
+                a = f(slots[t]) if slots[t] is not None else pad_addr
+                for b in (a % 32, (a + 1) % 32):
+                    banks.setdefault(b, {}).setdefault(a, []).append(t)
+            for by_addr in banks.values():
+                if len(by_addr) > 1:
+                    for ts in by_addr.values():
+                        bad.update(ts)
+        return sorted(bad)
+    cost = [gcost(g) for g in range(ng)]
+    floor = 0
+    for it in range(iters):
+        if sum(cost) <= floor:
+            break
+        # targeted move: a lane that takes part in a conflict, exchanged with a random lane of another 16-lane store group
+        sg = rng.randrange(4 * ng)
+        bad = sub_bad(sg)
+        if not bad:
+            continue
+        a, b = rng.choice(bad), rng.randrange(64 * ng)
+        ga, gb = a // 64, b // 64
+        if a // 16 == b // 16 or cnt(slots[a]) > gmax[gb] or cnt(slots[b]) > gmax[ga]:
+            continue
+        before = cost[ga] + (cost[gb] if gb != ga else 0)
+        slots[a], slots[b] = slots[b], slots[a]
+        ca, cb = gcost(ga), (gcost(gb) if gb != ga else 0)
+        if ca + cb <= before:
+            cost[ga] = ca
+            if gb != ga:
+                cost[gb] = cb
+        else:
+            slots[a], slots[b] = slots[b], slots[a]
+    return [slots[64 * g:64 * g + 64] for g in range(ng)]
 
 
 def cg(l1, m1, l2, m2, l, m):
@@ -216,19 +295,25 @@ def main():
     # S[x][y] = dP[x][y] + dP[y][x], pairs x <= y (x == y counted from both sides: coefficient doubled), offsets point at
     # the POWER entry (aggregate offset + nblk_l + 1).  *_pos: where the lane's result goes in the LDS matrix (float
     # index x * 52 + 2 y; pairs: both mirror positions, 16 bits each), CG_POS_DUMP for padding lanes.
-    LD = 52
+    LD = 52   # forward kernel: floats per row of its moment matrices (CGM_LD, cg_mfma.inc)
+    # adjoint kernel: its matrix is read as an MFMA A operand (lane (i, q) reads row i, column q + 4 s: ds_read_b32, banks mod
+    # 32 over 32-lane groups): with 52 floats per row the rows i and i + 8 meet on one bank (52 i mod 32 has 8 values) -- a
+    # 2-way conflict on every one of the 52 reads per item; any stride = 2 mod 4 spreads the 16 rows over 16 bank pairs
+    LDB = 54
     # padding lanes store their (zero) result into a spare word of the wave's LDS block: float index of entry 775 of the
-    # slice buffer that follows the 26 x 52 matrix (k_catbuild_bwd_mfma static_asserts this layout) -- no branch
-    POS_DUMP = 26 * LD + 2 * 775
-    def resolved(lanes, gmax, entries_of, pos_of, pad_pos):
+    # slice buffer that follows the 26 x LDB matrix (k_catbuild_bwd_mfma static_asserts this layout) -- no branch
+    POS_DUMP = 26 * LDB + 2 * 775
+    def resolved(lanes, counts, gmax, entries_of, pos_of, pad_pos, addr_fns):
         off, cf, pos = [], [], []
+        groups = order_for_stores(lanes, counts, gmax, addr_fns, POS_DUMP, 3000)
         for g, gm in enumerate(gmax):
-            grp = lanes[g * 64:(g + 1) * 64]
-            for row in deconflict([entries_of(k) for k in grp], gm, lambda o: 2 * o, 1000 + g):  # (complex offsets: 8 bytes)
+            grp = groups[g]
+            ents = [entries_of(k) if k is not None else [] for k in grp]
+            for row in deconflict(ents, gm, lambda o: 2 * o, 1000 + g):  # (complex offsets: 8 bytes)
                 for o, c in row:
                     off.append(o)
                     cf.append(c)
-            pos += [pos_of(grp[t]) if t < len(grp) else pad_pos for t in range(64)]
+            pos += [pos_of(k) if k is not None else pad_pos for k in grp]
         return off, cf, pos
     def key_entries(key):
         return [(g_pk[q] & 0xffff, t_terms[q][2]) for q in range(t_start[key], t_start[key + 1])]
@@ -240,10 +325,11 @@ def main():
             kb = y * 25 + x
             ent += [((g_pk[q] & 0xffff) + (g_pk[q] >> 16), t_terms[q][2]) for q in range(t_start[kb], t_start[kb + 1])]
         return ent
-    bk_off, bk_c, bk_pos = resolved(key_perm, key_gmax, key_entries, lambda k: (k // 25) * LD + 2 * (k % 25), POS_DUMP)
-    bp_off, bp_c, bp_pos = resolved(pair_perm, pair_gmax, pair_entries,
-                                    lambda k: ((k // 25) * LD + 2 * (k % 25)) | (((k % 25) * LD + 2 * (k // 25)) << 16),
-                                    POS_DUMP | (POS_DUMP << 16))
+    pos_xy = lambda k: (k // 25) * LDB + 2 * (k % 25)  # noqa: E731
+    pos_yx = lambda k: (k % 25) * LDB + 2 * (k // 25)  # noqa: E731
+    bk_off, bk_c, bk_pos = resolved(key_perm, {k: key_cnt[k] for k in range(625)}, key_gmax, key_entries, pos_xy, POS_DUMP, [pos_xy])
+    bp_off, bp_c, bp_pos = resolved(pair_perm, {pairs[i][0] * 25 + pairs[i][1]: pair_cnt[i] for i in range(len(pairs))}, pair_gmax,
+                                    pair_entries, lambda k: pos_xy(k) | (pos_yx(k) << 16), POS_DUMP | (POS_DUMP << 16), [pos_xy, pos_yx])
     assert len(bk_off) == 64 * sum(key_gmax) and len(bp_off) == 64 * sum(pair_gmax)
 
     # forward projection, staged per part of the channel slice (parts: l <= 2, l = 3, l = 4): one word per output row,
@@ -267,21 +353,26 @@ def main():
     part_base = [0, 251, 496]
     for part, ls in enumerate(((0, 1, 2), (3, ), (4, ))):
         rows = sorted((ri for ri in row_info if ri[0] in ls), key=lambda ri: -ri[2])
-        for g in range(0, len(rows), 64):
-            grp = rows[g:g + 64]
-            gm = max(ri[2] for ri in grp)
+        part_gmax = [max(ri[2] for ri in rows[g:g + 64]) for g in range(0, len(rows), 64)]
+        # which lane of which group takes which row: ordered against the bank conflicts of the two 8-byte stores into the stage
+        # (aggregate entry at the row's part-relative slice position, power entry nblk_l + 1 behind it)
+        part_groups = order_for_stores(list(range(len(rows))), {i: rows[i][2] for i in range(len(rows))}, part_gmax,
+                                       [lambda i: 2 * (rows[i][3] - part_base[part]), lambda i: 2 * (rows[i][3] - part_base[part] + rows[i][4])],
+                                       2 * FW_DUMP, 4000 + part)
+        for gi, gm in enumerate(part_gmax):
+            grp = [rows[i] if i is not None else None for i in part_groups[gi]]
             rowS_gmax.append(gm)
             rowS_part.append(part)
             for ri in grp:
-                rowS.append(ri[1] | (ri[2] << 11) | (ri[3] << 15) | (ri[4] << 25))
-            rowS += [1023 << 15] * (64 - len(grp))
-            ents = [[(terms[ri[1] + j][0] * LD + 2 * terms[ri[1] + j][1], terms[ri[1] + j][2]) for j in range(ri[2])] for ri in grp]
+                rowS.append((ri[1] | (ri[2] << 11) | (ri[3] << 15) | (ri[4] << 25)) if ri is not None else (1023 << 15))
+            ents = [[(terms[ri[1] + j][0] * LD + 2 * terms[ri[1] + j][1], terms[ri[1] + j][2]) for j in range(ri[2])] if ri is not None else []
+                    for ri in grp]
             for row in deconflict(ents, gm, lambda o: o, 2000 + len(rowS_gmax)):  # (float offsets of 8-byte entries)
                 for o, c in row:
                     fw_off.append(o)
                     fw_c.append(c)
             for t in range(64):
-                if t < len(grp):
+                if grp[t] is not None:
                     pos = grp[t][3] - part_base[part]
                     fw_pos.append(pos | ((pos + grp[t][4]) << 16))
                     l = grp[t][0]
@@ -328,6 +419,7 @@ def main():
     w(f'static const unsigned int h_cgFW_lbm[{len(fw_lbm)}] = {{' + ', '.join(map(str, fw_lbm)) + '};')
     w('#define CG_ROWS_SLOT0 {' + ', '.join(str(sum(rowS_gmax[:g])) for g in range(len(rowS_gmax))) + '}')
     w(f'#define CG_POS_DUMP {POS_DUMP}')
+    w(f'#define CG_BWD_LD {LDB}')
     w(f'#define CG_BK_SLOTS {sum(key_gmax)}')
     w(f'#define CG_BP_SLOTS {sum(pair_gmax)}')
     w(f'static const unsigned short h_cgBK_off[{len(bk_off)}] = {{' + ', '.join(map(str, bk_off)) + '};')

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # session-wide disk cache of ORACLE results (tests/helpers.py::oracle_backward); child interpreters of the forced-kernel
+    # tests inherit it through the environment
+    if 'MOLGYM_ORACLE_CACHE' not in os.environ:
+        import tempfile
+        os.environ['MOLGYM_ORACLE_CACHE'] = tempfile.mkdtemp(prefix='molgym_oracle_')
 
 
 @pytest.fixture(scope='session')

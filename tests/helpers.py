@@ -35,6 +35,53 @@ def make_pair(cfg_name='cfg2', seed=0, beta='cfg', device='cuda:0', dtype=torch.
     return ac, ref, cfg
 
 
+class _Grad:
+    def __init__(self, g):
+        self.grad = g
+
+
+def oracle_backward(ref, data, weights):
+    """The oracle side of an output + gradient comparison: exp = ref.step(obs, act) in float64 and the gradient of
+    sum(logp wl + ent we + v wv) w.r.t. every parameter -> (outputs dict, {name: object with .grad}).  The float64 oracle at
+    canvas 20 / 40 is most of such a test's time, and the forced-kernel variants of tests/test_gpu_parity_full.py re-run the same
+    cases in child interpreters: results are cached on disk for the session (MOLGYM_ORACLE_CACHE, set by conftest.py), keyed by
+    the weights, the inputs, the loss weights and the oracle's own sources -- the cache holds ORACLE results only, never the
+    product's."""
+    import hashlib
+    import os
+    wl, we, wv = weights
+    cache = os.environ.get('MOLGYM_ORACLE_CACHE')
+    path = None
+    if cache:
+        h = hashlib.sha1()
+        odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+        for f in sorted(os.listdir(odir)):
+            if f.endswith('.py'):
+                h.update(open(os.path.join(odir, f), 'rb').read())
+        h.update(type(ref).__name__.encode())
+        for k, v in sorted(ref.state_dict().items()):
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+        h.update(repr(data['obs']).encode())
+        h.update(np.ascontiguousarray(np.asarray(data['act'], dtype=np.float64)).tobytes())
+        for w in (wl, we, wv):
+            h.update(w.detach().cpu().double().numpy().tobytes())
+        path = os.path.join(cache, h.hexdigest() + '.pt')
+        if os.path.exists(path):
+            rec = torch.load(path)
+            return rec['exp'], {k: _Grad(g) for k, g in rec['grads'].items()}
+    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
+    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    if path is not None:
+        rec = {'exp': {k: exp[k].detach().clone() for k in ('logp', 'ent', 'v')},
+               'grads': {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in ref.named_parameters()}}
+        os.makedirs(cache, exist_ok=True)
+        tmp = f'{path}.{os.getpid()}.tmp'
+        torch.save(rec, tmp)
+        os.replace(tmp, path)
+    return exp, dict(ref.named_parameters())
+
+
 def rel_err(got, want, floor=1e-2, abs_tol=1e-6, tol=1e-5):
     """Worst elementwise error in units where `< tol` (1e-5 by default) means: TRUE relative error below `tol` wherever
     |want| >= floor (1e-2), absolute error below `abs_tol` (1e-6) for the smaller entries -- north_star's "1e-5 relative

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from molgym_amd.synthetic import make_batch
-from tests.helpers import assert_grads, grad_report, make_pair
+from tests.helpers import assert_grads, grad_report, make_pair, oracle_backward
 
 pytestmark = pytest.mark.gpu
 
@@ -18,10 +18,8 @@ def _grads(cfg_name, B, seed, beta='cfg', weights=(1.0, 0.3, 0.7)):
     loss = (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum()
     loss.backward()
     torch.cuda.synchronize()
-    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
-    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    _, want = oracle_backward(ref, data, (wl, we, wv))
     got = ac.theta.grad.detach().double().cpu()
-    want = dict(ref.named_parameters())
     return grad_report(got, want, ac.slot_table)
 
 

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from molgym_amd.synthetic import make_batch
-from tests.helpers import assert_grads, grad_report, make_pair, rel_err
+from tests.helpers import assert_grads, grad_report, make_pair, oracle_backward, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -22,12 +22,10 @@ def _compare(cfg_name, B, seed, weights=(1.0, 0.3, 0.7), data=None):
     out = ac.step(data['obs'], data['act'])
     (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
     torch.cuda.synchronize()
-    exp = ref.step(data['obs'], data['act'], dtype=torch.float64)
-    (exp['logp'] * wl + exp['ent'] * we + exp['v'] * wv).sum().backward()
+    exp, want = oracle_backward(ref, data, (wl, we, wv))
     for k in ('logp', 'ent', 'v'):
         assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
     got = ac.theta.grad.detach().double().cpu()
-    want = dict(ref.named_parameters())
     assert_grads(grad_report(got, want, ac.slot_table))
     return ac, cfg, data
 
@@ -77,85 +75,75 @@ def test_sf6_full_minibatch_140_vs_oracle(built_lib):
     assert int(ac.workspace_view_int('err', ac._make_cfg(140, natoms))[0]) == 0
 
 
-@pytest.mark.gpu
-def test_shared_dot_block_layout_vs_oracle(built_lib):
-    """With many edges (>= 16384) the edge levels keep ONE copy of the DotMatrix block and run the shared-input MFMA
-    kernels (gemm.inc: k_gemm_mfma_sx / k_gemm_mfma_pk, segmented weight-gradient inputs).  The oracle cannot reach that
-    size in seconds, so the same kernels are forced on the small oracle cases (MG_SX_MIN_ROWS=1, read once per process:
-    hence the child interpreter)."""
+# ---- kernels that only run at sizes the oracle does not reach in seconds: forced on the small oracle cases --------------------------
+# Their switches are read once per process, hence child interpreters.  ALL children are started together by whichever of the
+# tests below runs first (round 5 ran them one after the other: 254 s of a 635 s suite); they share the GPU with the parent's
+# own tests and the oracle results of a case are computed once per session (tests/helpers.py::oracle_backward: disk cache
+# keyed by the weights, the inputs and the oracle's sources).
+_FORCED = {
+    # With many edges (>= 16384) the edge levels keep ONE copy of the DotMatrix block and run the shared-input MFMA kernels
+    # (gemm.inc: k_gemm_mfma_sx / k_gemm_mfma_pk, segmented weight-gradient inputs): MG_SX_MIN_ROWS=1; MG_SX_WS=0: the
+    # wave-per-16-rows kernel, MG_SX_WS=2: the LDS-stationary-weights kernel of the large row counts (round 5)
+    'sx0': (dict(MG_SX_MIN_ROWS='1', MG_SX_WS='0'), ('parity_full', 'backward', 'forward'),
+            'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or encoder_stages'),
+    'sx2': (dict(MG_SX_MIN_ROWS='1', MG_SX_WS='2'), ('parity_full', 'backward', 'forward'),
+            'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or encoder_stages'),
+    # The adjoints of the atom cat-mixes w.r.t. their concatenated inputs run a weight-stationary kernel from 4096 row tiles
+    # (gemm.inc: k_gemm_mfma_cols_ws): R = 20 / 24 / 40 (hidden levels; last level of Z = 3 and Z = 5), partial last row tiles,
+    # one row-tile chunk per workgroup
+    'cols_ws': (dict(MG_COLS_WS_MIN_TILES='1', MG_COLS_WS_WGS='64'), ('parity_full', 'backward'),
+                'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or canvas12'),
+    # [r5] the LDS-stationary-weights row GEMM of the atom cat-mixes (gemm.inc: k_gemm_mfma_rows_ws; MG_ROWS_WS=2 also takes the
+    # 40-wide last-level mixes of Z = 5) and the opt-in molecule-stationary CG adjoint (backward.inc: k_catbuild_bwd_mol)
+    'r5_large': (dict(MG_ROWS_WS_MIN='1', MG_ROWS_WS='2', MG_CGB_MOL='0'), ('parity_full', 'backward'),
+                 'canvas20_crowded or canvas40_crowded or sf6_full or grads_five'),
+    # [r5] MG_CATMIX_EPI=1: the atom cat-mix of the levels >= 1 as the epilogue of the CG kernel (cg_mfma.inc: CgMix) instead of
+    # the row GEMM launch -- off by default (measured neutral)
+    'catmix_epi': (dict(MG_CATMIX_EPI='1'), ('parity_full', 'backward', 'forward'),
+                   'sf6_full or grads_cfg2 or encoder_stages or canvas12'),
+}
+_CHILD = {}
+
+
+def _forced_child(name):
     import os
     import subprocess
     import sys
+    import tempfile
     here = os.path.dirname(os.path.abspath(__file__))
-    # (MG_SX_WS=0: the wave-per-16-rows kernel; MG_SX_WS=2: the LDS-stationary-weights kernel of the large row counts, round 5,
-    # forced at these sizes)
-    for sx_ws in ('0', '2'):
-        env = dict(os.environ, MG_SX_MIN_ROWS='1', MG_SX_WS=sx_ws)
-        r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
-                            os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
-                            os.path.join(here, 'test_gpu_forward.py'),
-                            '-k', 'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or encoder_stages'],
-                           env=env, capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-        assert ' passed' in r.stdout and 'deselected' in r.stdout
+    if not _CHILD:
+        for nm, (env, files, kexpr) in _FORCED.items():
+            log = tempfile.NamedTemporaryFile('w+', prefix=f'forced_{nm}_', suffix='.log', delete=False)
+            cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider'] + \
+                  [os.path.join(here, f'test_gpu_{f}.py') for f in files] + ['-k', kexpr]
+            _CHILD[nm] = (subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=log, stderr=subprocess.STDOUT, text=True), log)
+    proc, log = _CHILD[name]
+    try:
+        rc = proc.wait(timeout=1500)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        raise
+    log.seek(0)
+    text = log.read()
+    assert rc == 0, f'{name} {_FORCED[name][0]}: ' + text[-4000:]
+    assert ' passed' in text and 'deselected' in text, text[-2000:]
+
+
+@pytest.mark.parametrize('sx_ws', ['sx0', 'sx2'])
+def test_shared_dot_block_layout_vs_oracle(built_lib, sx_ws):
+    _forced_child(sx_ws)
 
 
 def test_weight_stationary_column_gemm_vs_oracle(built_lib):
-    """The adjoints of the atom cat-mixes w.r.t. their concatenated inputs run a weight-stationary kernel from 4096 row tiles
-    (gemm.inc: k_gemm_mfma_cols_ws; a wave keeps the weight operands of its column tiles in registers and walks row tiles).  The
-    oracle does not reach that size in seconds (the masked full-size comparison of tests/test_gpu_large.py does run it), so the
-    same kernel is forced on the small oracle cases (MG_COLS_WS_MIN_TILES=1, read once per process: hence the child interpreter):
-    R = 20 / 24 / 40 (hidden levels; last level of Z = 3 and Z = 5), partial last row tiles, one row-tile chunk per workgroup."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MG_COLS_WS_MIN_TILES='1', MG_COLS_WS_WGS='64')
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
-                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
-                        '-k', 'canvas20_crowded or canvas40_crowded or sf6_full or grads_cfg2 or grads_five or canvas12'],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout and 'deselected' in r.stdout
+    _forced_child('cols_ws')
 
 
 def test_round5_forced_large_batch_kernels_vs_oracle(built_lib):
-    """[r5] Two kernels that only run at row / edge counts the oracle does not reach in seconds, forced on the small oracle cases in
-    ONE child interpreter (their switches are read once per process): the LDS-stationary-weights row GEMM of the atom cat-mixes
-    (gemm.inc: k_gemm_mfma_rows_ws; MG_ROWS_WS_MIN=1, MG_ROWS_WS=2 also takes the 40-wide last-level mixes of Z = 5 that leave room
-    for one 8-wave workgroup per CU) and the opt-in molecule-stationary CG adjoint (backward.inc: k_catbuild_bwd_mol; MG_CGB_MOL=0 =
-    from zero edges).  Outputs and every parameter gradient against the oracle (the masked full-size comparison of
-    tests/test_gpu_large.py runs rows_ws at its real sizes)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MG_ROWS_WS_MIN='1', MG_ROWS_WS='2', MG_CGB_MOL='0')
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
-                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
-                        '-k', 'canvas20_crowded or canvas40_crowded or sf6_full or grads_five'],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout and 'deselected' in r.stdout
+    _forced_child('r5_large')
 
 
 def test_catmix_epilogue_vs_oracle(built_lib):
-    """[r5] MG_CATMIX_EPI=1: the atom cat-mix of the levels >= 1 as the epilogue of the CG kernel (cg_mfma.inc: CgMix; partial sums of
-    the channel-waves by float atomics into representations zeroed by k_edge_fwd) instead of the row GEMM launch -- off by default
-    (measured neutral), read once per process: hence the child interpreter.  Outputs, every saved stage and every gradient of the SF6
-    mini-batch and the canvas-12 case against the oracle (the one-launch-per-level kernels of the small mini-batches carry it)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MG_CATMIX_EPI='1')
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
-                        os.path.join(here, 'test_gpu_parity_full.py'), os.path.join(here, 'test_gpu_backward.py'),
-                        os.path.join(here, 'test_gpu_forward.py'),
-                        '-k', 'sf6_full or grads_cfg2 or encoder_stages or canvas12'],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout and 'deselected' in r.stdout
+    _forced_child('catmix_epi')
 
 
 def test_other_channel_counts_vs_oracle(built_lib):
