@@ -135,9 +135,10 @@ class CovariantAC(FlatThetaAgent):
         device=None,
     ):
         super().__init__(observation_space, action_space)
-        if maxl != layout.MAXL:
-            raise RuntimeError('the gfx950 kernels are built for maxl=4 (the reference default, arg_parser.py:55; every BASELINE '
-                               'config uses it): the Clebsch-Gordan tables, thread maps and LDS layouts are laid out for 25 (l, m) rows')
+        if not 1 <= int(maxl) <= layout.MAXL:
+            raise RuntimeError(f'maxl {maxl}: the gfx950 kernels cover 1..{layout.MAXL} (the Clebsch-Gordan tables, thread maps and LDS '
+                               f'layouts are laid out for the 25 (l, m) rows of maxl = 4, the reference default, arg_parser.py:56; a '
+                               f'smaller maxl runs as the same network with the higher degrees structurally zero)')
         if not _lib.LEVELS_RANGE[0] <= int(num_cg_levels) <= _lib.LEVELS_RANGE[1]:
             raise RuntimeError(f'num_cg_levels {num_cg_levels}: the kernels cover {_lib.LEVELS_RANGE[0]}..{_lib.LEVELS_RANGE[1]}')
         # the channel counts and num_cg_levels are compile-time constants of a library build: the defaults load
@@ -157,10 +158,20 @@ class CovariantAC(FlatThetaAgent):
             raise RuntimeError(f'network_width {network_width}: the HIP heads kernels support multiples of 4 up to 1024')
         self.num_gaussians, self.network_width, self.bag_scale = num_gaussians, network_width, bag_scale
         self.num_channels_out = len(self.zs) * num_channels_per_element
-        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)  # (C, Ce, levels)
+        self.slot_table, total = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels, int(maxl))  # (C, Ce, levels, maxl)
         self._L()  # load (build) the library for these channel counts now: a missing toolchain fails here, not mid-rollout
         self.theta = torch.nn.Parameter(self._init_theta(total))
         self.register_buffer('leb', torch.from_numpy(lebedev_table()), persistent=False)
+        # [r6] maxl < 4 (arg_parser.py:56): theta / state_dict are the maxl-limited module's (the reference's shapes); the kernels
+        # read the maxl = 4 layout, into which theta is EMBEDDED -- the smaller network is the larger one with every quantity of a
+        # degree above maxl multiplied by a zero weight, so outputs are those of the smaller network and its gradient is the gather
+        # of the larger one's (layout.embedding_index; exact: tests/test_host.py checks it on the oracle, the GPU tests against the
+        # oracle built with the same maxl).  Not faster than maxl = 4: the kernels still walk the 25 (l, m) rows.
+        if int(maxl) < layout.MAXL:
+            _, total_k = layout.offsets(len(self.zs), network_width, num_gaussians, *self._channels)
+            idx = layout.embedding_index(len(self.zs), network_width, num_gaussians, *self._channels, int(maxl))
+            self.register_buffer('_embed_idx', torch.from_numpy(idx), persistent=False)
+            self.register_buffer('_theta_k', torch.zeros(total_k), persistent=False)
         self._last_ws = None
         # ppo_minibatch issues its launches as one updated hipGraph launch (include/molgym_hip.h: mg_cov_ppo_step)
         self.use_graphs = True
@@ -173,6 +184,35 @@ class CovariantAC(FlatThetaAgent):
         """the library build for this agent's channel counts"""
         return _lib.lib(getattr(self, '_channels', None))
 
+    # -- the parameter vector the KERNELS read (maxl = 4 layout) and the gradient buffer they add into ----------------------
+    def _ktheta(self, refresh: bool = True) -> torch.Tensor:
+        if self.max_sh == layout.MAXL:
+            return self.theta
+        if refresh:  # (positions outside the index are zero from construction and never written; rewriting equal values is
+            with torch.no_grad():  # harmless to a kernel of another stream that reads them meanwhile)
+                self._theta_k.index_copy_(0, self._embed_idx, self.theta.detach())
+        return self._theta_k
+
+    def _kgrad(self, slot: int = 0) -> torch.Tensor:
+        if self.max_sh == layout.MAXL:
+            return self.theta.grad
+        bufs = self.__dict__.setdefault('_grad_k', {})
+        if slot not in bufs or bufs[slot].device != self.theta.device:
+            bufs[slot] = torch.zeros_like(self._theta_k)
+        return bufs[slot]
+
+    def _kgrad_collect(self, slot: int) -> None:
+        """maxl < 4: theta.grad += gather of the slot's kernel-side gradient buffer (float atomics: mini-batches of other
+        streams may be adding to theta.grad too), buffer zeroed for its next use"""
+        if self.max_sh == layout.MAXL:
+            return
+        gk = self._grad_k[slot]
+        iota = self.__dict__.get('_iota')
+        if iota is None or iota.device != self.theta.device:
+            iota = self._iota = torch.arange(self.theta.numel(), device=self.theta.device)
+        self.theta.grad.index_add_(0, iota, gk.index_select(0, self._embed_idx))
+        gk.zero_()
+
     # whole-module pickling (ModelIO.save = torch.save(module), tools/model_util.py:82-91): drop the caches
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -182,6 +222,8 @@ class CovariantAC(FlatThetaAgent):
         state.pop('_ws_epoch', None)
         state.pop('_unchecked', None)
         state.pop('_last_out', None)
+        state.pop('_grad_k', None)
+        state.pop('_iota', None)
         return state
 
     # -- parameters -----------------------------------------------------------------------------
@@ -271,7 +313,10 @@ class CovariantAC(FlatThetaAgent):
         acts = self._check_actions(actions, B)
         cfg = self._make_cfg(B, natoms)
         d_pos, d_chg, d_bag, d_act = self._upload_packed(pos, charges, bags, acts)
-        out = _CovStep.apply(self.theta, self, cfg, d_pos, d_chg, d_bag, d_act)
+        theta = self.theta
+        if self.max_sh != layout.MAXL:  # (differentiable embedding: autograd gathers the gradient back)
+            theta = torch.zeros_like(self._theta_k).index_copy(0, self._embed_idx, self.theta)
+        out = _CovStep.apply(theta, self, cfg, d_pos, d_chg, d_bag, d_act)
         return {'a': d_act, 'logp': out[0], 'ent': out[1], 'v': out[2],
                 'dists': self._dists(cfg, self._last_ws, d_bag)}
 
@@ -322,6 +367,7 @@ class CovariantAC(FlatThetaAgent):
     # ---- what depends on theta alone, once per EPOCH instead of once per mini-batch (ppo.py:117-146: one optimizer step per epoch) ----
     def invalidate_weights(self) -> None:
         """theta may have changed (start of a PPO epoch): the derived weight matrices cached in the workspaces are stale"""
+        self._ktheta()  # (maxl < 4: re-embed theta, on the caller's stream -- ppo._DeviceRunner.begin_epoch orders the others behind it)
         for st in self.__dict__.get('_ws_epoch', {}).values():
             st['weights'] = False
             # A slot still pending HERE was left by an epoch that never reached its fold (an exception between its mini-batches
@@ -343,7 +389,8 @@ class CovariantAC(FlatThetaAgent):
             if st.get('pending'):
                 ws = self._ws_cache[slot_]
                 with self._guard():
-                    self._chk(self._L().mg_cov_fold_grads(C.byref(st['cfg']), _ptr(ws), ws.numel(), _ptr(self.theta.grad), self._s()))
+                    self._chk(self._L().mg_cov_fold_grads(C.byref(st['cfg']), _ptr(ws), ws.numel(), _ptr(self._kgrad(slot_)), self._s()))
+                self._kgrad_collect(slot_)
                 ws.record_stream(torch.cuda.current_stream(self.theta.device))
                 st['pending'] = False
 
@@ -352,7 +399,7 @@ class CovariantAC(FlatThetaAgent):
         ws = self._workspace(batch.cfg, slot)
         out = torch.empty(3, batch.cfg.B, dtype=torch.float32, device=self.theta.device)
         with self._guard():
-            self._chk(self._L().mg_cov_forward(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos),
+            self._chk(self._L().mg_cov_forward(C.byref(batch.cfg), _ptr(self._ktheta()), _ptr(batch.pos),
                                                  _ptr(batch.charges), _ptr(batch.bags), _ptr(batch.actions),
                                                  _ptr(self.leb), _ptr(ws), ws.numel(), _ptr(out), self._s()))
         self._last_ws, self._last_cfg = ws, batch.cfg
@@ -434,12 +481,15 @@ class CovariantAC(FlatThetaAgent):
             self.theta.grad = torch.zeros_like(self.theta)
         use_graph = self.use_graphs if graph is None else graph
         used = C.c_int32(0)
+        theta_k = self._ktheta(refresh=not (flags & _lib.STEP_WEIGHTS_CURRENT))
         with self._guard():
-            self._chk(lib.mg_cov_ppo_step(C.byref(batch.cfg), _ptr(self.theta), _ptr(batch.pos), _ptr(batch.charges),
+            self._chk(lib.mg_cov_ppo_step(C.byref(batch.cfg), _ptr(theta_k), _ptr(batch.pos), _ptr(batch.charges),
                                           _ptr(batch.bags), _ptr(batch.actions), _ptr(self.leb), _ptr(ws), ws.numel(),
                                           _ptr(batch.logp), _ptr(batch.adv), _ptr(batch.ret), clip_ratio, vf_coef, entropy_coef,
                                           float(loss_scale), _ptr(out), _ptr(gout), _ptr(stats), _ptr(stats_accum),
-                                          _ptr(self.theta.grad), slot if use_graph else -1, flags, C.byref(used), self._s()))
+                                          _ptr(self._kgrad(slot)), slot if use_graph else -1, flags, C.byref(used), self._s()))
+        if not epoch_cache:
+            self._kgrad_collect(slot)  # (maxl < 4; with epoch_cache the gather follows the fold, fold_gradients)
         self._last_ws, self._last_cfg, self._last_out = ws, batch.cfg, out
         self.last_step_used_graph = bool(used.value)
         self.__dict__.setdefault('_unchecked', {})[slot] = (batch.cfg, ws)
@@ -460,7 +510,7 @@ class CovariantAC(FlatThetaAgent):
         seed = int(torch.randint(0, 2**62, (1, )).item())  # follows torch.manual_seed (util.set_seeds)
         mode = 1 if self.training else 2
         with self._guard():
-            self._chk(self._L().mg_cov_sample(C.byref(cfg), _ptr(self.theta), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
+            self._chk(self._L().mg_cov_sample(C.byref(cfg), _ptr(self._ktheta()), _ptr(d_pos), _ptr(d_chg), _ptr(d_bag),
                                                 _ptr(self.leb), C.c_uint64(seed), mode, _ptr(ws), ws.numel(),
                                                 _ptr(acts), _ptr(out), self._s()))
         self._last_ws, self._last_cfg = ws, None
@@ -501,7 +551,7 @@ class CovariantAC(FlatThetaAgent):
             seed = self.draw_seed()
         mode = 1 if self.training else 2
         with self._guard():
-            self._chk(self._L().mg_cov_sample_ids(C.byref(cfg), _ptr(self.theta), _ptr(canvas.pos32), _ptr(canvas.charges),
+            self._chk(self._L().mg_cov_sample_ids(C.byref(cfg), _ptr(self._ktheta()), _ptr(canvas.pos32), _ptr(canvas.charges),
                                                     _ptr(canvas.bags), _ptr(self.leb), C.c_uint64(seed), int(sample_ids[0]),
                                                     int(sample_ids[1]), mode, _ptr(ws), ws.numel(), _ptr(acts), _ptr(out),
                                                     self._s()))

@@ -208,6 +208,53 @@ def test_network_width_256_vs_oracle(built_lib):
     assert (g_dev - ac.theta.grad).abs().max().item() <= 2e-4 * ac.theta.grad.abs().max().item()
 
 
+@pytest.mark.parametrize('maxl', [3, 2])
+def test_other_maxl_vs_oracle(built_lib, maxl):
+    """[r6] --maxl 3 / 2 (arg_parser.py:56; 4 is the default and what every BASELINE config uses): theta and state_dict have the
+    maxl-limited module's shapes, the kernels read its embedding into the maxl = 4 layout (CovariantAC._ktheta,
+    layout.embedding_index; exactness of the embedding itself: tests/test_host.py).  Outputs and every parameter gradient
+    against the oracle BUILT WITH THE SAME maxl, the PPO mini-batch call (one graph launch, gradient gathered back) against the
+    autograd path, the epoch-cached form of it, and the rollout's sampling launch."""
+    ac, ref, cfg = make_pair('cfg2', seed=29, maxl=maxl)
+    assert ac.theta.numel() == sum(p.numel() for p in ref.parameters()) < 185006
+    data = make_batch(12, cfg['canvas_size'], cfg['zs'], seed=39)
+    B = len(data['obs'])
+    g = torch.Generator().manual_seed(5)
+    wl, we, wv = (torch.randn(B, generator=g, dtype=torch.float64) * s for s in (1.0, 0.3, 0.7))
+    out = ac.step(data['obs'], data['act'])
+    (out['logp'].double() * wl.cuda() + out['ent'].double() * we.cuda() + out['v'].double() * wv.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    exp, want = oracle_backward(ref, data, (wl, we, wv))
+    for k in ('logp', 'ent', 'v'):
+        assert rel_err(out[k].detach(), exp[k].detach()) < 1e-5, (k, rel_err(out[k].detach(), exp[k].detach()))
+    assert_grads(grad_report(ac.theta.grad.detach().double().cpu(), want, ac.slot_table))
+    # the one-call mini-batch step (plain, and with the per-epoch weight preparation / deferred fold of ppo.train) == autograd path
+    from molgym_amd import ppo as ppo_mod
+    ac.theta.grad = None
+    loss, info = ppo_mod.compute_loss(ac, data, 0.2, 0.5, 0.01)
+    loss.backward()
+    torch.cuda.synchronize()
+    g_auto = ac.theta.grad.detach().clone()
+    batch = ac.prepare_batch(data['obs'], data['act'], data['logp'], data['adv'], data['ret'])
+    for epoch_cache in (False, True):
+        ac.theta.grad = torch.zeros_like(ac.theta)
+        ac.invalidate_weights()
+        stats = ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=0.5, epoch_cache=epoch_cache).clone()
+        ac.ppo_minibatch(batch, 0.2, 0.5, 0.01, loss_scale=0.5, epoch_cache=epoch_cache)
+        ac.fold_gradients()
+        torch.cuda.synchronize()
+        assert (ac.theta.grad - g_auto).abs().max().item() <= 2e-5 * max(1.0, g_auto.abs().max().item()), epoch_cache
+        assert abs(stats[3].item() - info['total_loss']) <= 1e-6 * max(1.0, abs(info['total_loss']))
+    # rollout side: the sampling launch reads the embedded parameters too; what it reports for its draws is what evaluation gives
+    ac.training = True
+    torch.manual_seed(0)
+    drawn = ac.step(data['obs'])
+    again = ac.step(data['obs'], drawn['a'].cpu().numpy())
+    assert (drawn['logp'] - again['logp']).abs().max().item() < 1e-4 and (drawn['v'] - again['v']).abs().max().item() < 1e-5
+    sd = ac.state_dict()
+    assert all(tuple(sd[k].shape) == tuple(v.shape) for k, v in ref.state_dict().items() if k in sd)
+
+
 @pytest.mark.parametrize('levels', [2, 4])
 def test_other_num_cg_levels_vs_oracle(built_lib, levels):
     """num_cg_levels = 2 / 4 (arg_parser.py:56 makes it a command-line flag; 3 is the default): a build parameter of the

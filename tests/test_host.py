@@ -253,3 +253,46 @@ print('asan clean')
     r = subprocess.run([sys.executable, '-c', script, root, str(pkg)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and 'asan clean' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert 'AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize('maxl', [3, 2, 1])
+def test_maxl_embedding_is_exact_on_the_oracle(maxl):
+    """[r6] --maxl below 4 (arg_parser.py:56): CovariantAC keeps the maxl-limited parameter vector (the reference's state_dict
+    shapes) and hands the kernels its EMBEDDING into the maxl = 4 layout (layout.embedding_index).  The claim that makes this
+    exact -- the smaller network is the larger one with every quantity of a degree above maxl multiplied by a zero weight -- is
+    checked here on the oracle alone (float64, CPU): outputs and the gathered gradient of the embedded maxl = 4 oracle equal
+    those of the maxl-limited oracle; and the parameter layout equals the maxl-limited oracle module's state_dict."""
+    import numpy as np
+    import torch
+    from molgym_amd import layout
+    from molgym_amd.synthetic import CONFIGS, MODEL_DEFAULTS, make_batch
+    from oracle.covariant_ref import CovariantACRef
+    cfg = CONFIGS['cfg2']
+    Z = len(cfg['zs'])
+    data = make_batch(5, cfg['canvas_size'], cfg['zs'], seed=3)
+    torch.manual_seed(maxl)
+    kw = dict(MODEL_DEFAULTS, maxl=maxl)
+    common = dict(zs=cfg['zs'], canvas_size=cfg['canvas_size'], bag_scale=cfg['bag_scale'], beta=cfg['beta'])
+    small = CovariantACRef(**common, **kw).double()
+    big = CovariantACRef(**common, **MODEL_DEFAULTS).double()
+    ts, ns = layout.offsets(Z, 128, 3, 10, 4, 3, maxl)
+    tb, nb = layout.offsets(Z, 128, 3, 10, 4, 3, 4)
+    sd = small.state_dict()
+    assert ns == sum(p.numel() for p in small.parameters()) and all(tuple(sd[k].shape) == tuple(s) for k, (_, s) in ts.items())
+    idx = torch.from_numpy(layout.embedding_index(Z, 128, 3, 10, 4, 3, maxl))
+    assert len(idx) == ns and len(torch.unique(idx)) == ns and int(idx.max()) < nb
+    ps, pb = dict(small.named_parameters()), dict(big.named_parameters())
+    flat = torch.zeros(nb, dtype=torch.float64)
+    flat[idx] = torch.cat([ps[k].detach().reshape(-1) for k in ts])
+    big.load_state_dict({k: flat[o:o + int(np.prod(s))].view(s).clone() for k, (o, s) in tb.items()}, strict=False)
+    w = torch.randn(5, dtype=torch.float64)
+    grads = []
+    for ref, table, params in ((small, ts, ps), (big, tb, pb)):
+        out = ref.step(data['obs'], data['act'], dtype=torch.float64)
+        (out['logp'] * w + out['v'] + 0.1 * out['ent']).sum().backward()
+        grads.append((out, torch.cat([(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).reshape(-1)
+                                      for k in table])))
+    (os_, gs), (ob, gb) = grads
+    for k in ('logp', 'ent', 'v'):
+        assert (os_[k] - ob[k]).abs().max().item() <= 1e-12, k
+    assert (gs - gb[idx]).abs().max().item() <= 1e-12 * max(1.0, gs.abs().max().item())

@@ -7,6 +7,7 @@
 //  each with the buffer just written by another kernel ("dirty") and after a 1 GB eviction sweep ("cold")
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 __global__ void k_fill(float4* p, size_t n4) {
@@ -57,8 +58,10 @@ __global__ __launch_bounds__(256) void k_rows_contig(const float* X, int rows, i
   }
   if (s == 12345.f) out[0] = s;
 }
-int main() {
-  const int rows = 142560 * 1, R = 704, ld = 704;   // ~ the cfg3 l = 3 / 4 row blocks: 401 MB
+int main(int argc, char** argv) {
+  // ~ the cfg3 l = 3 / 4 row blocks: 401 MB; `rowstream 6` = the cfg5 size (2.4 GB), where the launches last 0.5 - 3 ms
+  const int mult = argc > 1 ? atoi(argv[1]) : 1;
+  const int rows = 142560 * mult, R = 704, ld = 704;
   const size_t n = (size_t)rows * ld, n4 = n / 4;
   float *X, *out; float4* evict;
   const size_t ev4 = (size_t)1 << 26;  // 1 GB
@@ -74,6 +77,7 @@ int main() {
     }
     printf("%-34s %s  best %.1f us  mean %.1f us  %.2f TB/s (best)\n", name, mode == 0 ? "dirty" : "cold ", best * 1e3, sum / (reps - 1) * 1e3, n * 4 / (best * 1e-3) / 1e12);
   };
+  printf("rows %d x %d floats = %.0f MB\n", rows, ld, n * 4 / 1e6);
   for (int mode = 0; mode < 2; ++mode) {
     timeit("A linear float4", mode, [&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (const float4*)X, n4, out); });
     timeit("B mfma pattern, 2 blocks / trip", mode, [&] { hipLaunchKernelGGL(k_rows_mfma<2>, dim3(1114), dim3(256), 0, 0, X, rows, R, ld, out); });
