@@ -170,7 +170,10 @@ def test_graph_step_equals_stream_launches(built_lib):
         with torch.no_grad():
             ac.theta.copy_(theta0)
         ac.use_graphs = mode
-        opt = torch.optim.Adam(ac.parameters(), lr=3e-4)
+        # (SGD: linear in the gradient.  Adam's step is ~ lr g / |g| per entry: where g ~ 0 the run-to-run order of the float atomics
+        # decides a sign and the two runs part by up to 2 lr -- the round-6 run failed this comparison at 8.8e-5 with no kernel of the
+        # step changed in what it computes)
+        opt = torch.optim.SGD(ac.parameters(), lr=0.05)
         np.random.seed(6)
         info = ppo.train(ac, opt, data, mini_batch_size=16, clip_ratio=0.2, target_kl=1e9, vf_coef=0.5, entropy_coef=0.01,
                          gradient_clip=0.5, max_num_steps=2)
