@@ -87,8 +87,9 @@ def _build_key(channels):
     return key if len(key) == 3 else key + (DEFAULT_LEVELS, )
 
 
-ABI_VERSION = 9
-STEP_WEIGHTS_CURRENT, STEP_DEFER_FOLD = 1, 2  # include/molgym_hip.h MG_STEP_*: flags of mg_cov_ppo_step  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+ABI_VERSION = 9  # include/molgym_hip.h MG_ABI_VERSION: bumped whenever an entry point or the workspace layout changes
+# include/molgym_hip.h MG_STEP_*: flags of mg_cov_ppo_step; mg_int_ppo_step takes WEIGHTS_CURRENT only (DEFER_FOLD: EINVAL there)
+STEP_WEIGHTS_CURRENT, STEP_DEFER_FOLD = 1, 2
 
 
 def _bind(path):
