@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void k_rows_contig(const float* X, int rows, i
 int main(int argc, char** argv) {
   // ~ the cfg3 l = 3 / 4 row blocks: 401 MB; `rowstream 6` = the cfg5 size (2.4 GB), where the launches last 0.5 - 3 ms
   const int mult = argc > 1 ? atoi(argv[1]) : 1;
-  const int rows = 142560 * mult, R = 704, ld = 704;
+  // (`rowstream 1 12768`: the 35 MB of one level's rows at the SF6 mini-batch -- 12750 rows of up to 704 floats)
+  const int rows = argc > 2 ? atoi(argv[2]) : 142560 * mult, R = 704, ld = 704;
   const size_t n = (size_t)rows * ld, n4 = n / 4;
   float *X, *out; float4* evict;
   const size_t ev4 = (size_t)1 << 26;  // 1 GB
