@@ -704,7 +704,10 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
   static int fuse_loss = -1;
   if (fuse_loss < 0) { const char* e = getenv("MG_FUSED_LOSS"); fuse_loss = e ? atoi(e) : 1; }
   auto run = [&]() -> int {
-    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum};
+    // MG_FUSED_LOSS: 1 (default) = the sample's own coefficients in k_heads_fwd, the statistics as a rider of k_heads_bwd [r6];
+    // 2 = both in the last workgroup of k_heads_fwd (round 4 / 5); 0 = the loss as its own launch
+    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum,
+                            fuse_loss == 1 ? 1 : 0};
     bool fused = false;
     int rc = cov_forward_impl(c, theta, pos, charges, bags, const_cast<float*>(actions), leb, ws, ws_bytes, out, stream, nullptr,
                               fuse_loss ? &la : nullptr, &fused, flags);
@@ -714,8 +717,9 @@ extern "C" int mg_cov_ppo_step(const mg_cov_cfg* c, const float* theta, const fl
                          entropy_coef, stats, gout, loss_scale, stats_accum);
       LAUNCH_CHECK();
     }
+    const bool rider = fused && la.defer_stats;
     return cov_backward_impl(c, theta, pos, charges, bags, actions, leb, ws, ws_bytes, gout, grad_theta, stream,
-                             (flags & MG_STEP_DEFER_FOLD) != 0);
+                             (flags & MG_STEP_DEFER_FOLD) != 0, rider ? &la : nullptr, rider ? out : nullptr);
   };
   if (used_graph) *used_graph = 0;
   static int graphs_on = -1;
