@@ -776,7 +776,9 @@ extern "C" int mg_int_ppo_step(const mg_int_cfg* c, const float* theta, const in
   auto run = [&]() -> int {
     static int fuse_loss = -1;
     if (fuse_loss < 0) { const char* e = getenv("MG_FUSED_LOSS"); fuse_loss = e ? atoi(e) : 1; }
-    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum};
+    // (MG_FUSED_LOSS as in mg_cov_ppo_step: 1 = coefficients per sample in k_int_heads_eval, statistics as a rider of its adjoint)
+    const PpoLossArgs la = {old_logp, adv, ret, clip_ratio, vf_coef, entropy_coef, loss_scale, stats, gout, stats_accum,
+                            fuse_loss == 1 ? 1 : 0};
     int rc = int_forward_impl(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, out, stream, fuse_loss ? &la : nullptr, flags);
     if (rc) return rc;
     if (!fuse_loss) {
@@ -784,7 +786,9 @@ extern "C" int mg_int_ppo_step(const mg_int_cfg* c, const float* theta, const in
                          entropy_coef, stats, gout, loss_scale, stats_accum);
       LAUNCH_CHECK();
     }
-    return mg_int_backward(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, gout, grad_theta, stream);
+    const bool rider = fuse_loss == 1;
+    return int_backward_impl(c, theta, mol_off, edge_off, molZ, molpos, bags, actions, ws, ws_bytes, gout, grad_theta, stream,
+                             rider ? &la : nullptr, rider ? out : nullptr);
   };
   if (used_graph) *used_graph = 0;
   static int graphs_on = -1;
