@@ -101,6 +101,10 @@ _FORCED = {
     # the row GEMM launch -- off by default (measured neutral)
     'catmix_epi': (dict(MG_CATMIX_EPI='1'), ('parity_full', 'backward', 'forward'),
                    'sf6_full or grads_cfg2 or encoder_stages or canvas12'),
+    # [r6] the two older placements of the PPO loss (MG_FUSED_LOSS=2: coefficients and statistics in the last workgroup of
+    # k_heads_fwd; 0: the loss as its own launch) against the same oracle / autograd comparisons the default placement runs
+    'loss_in_fwd_tail': (dict(MG_FUSED_LOSS='2'), ('ppo', 'internal'), 'fused_minibatch or ppo_loss_kernel or graph_step or ppo_minibatch'),
+    'loss_own_launch': (dict(MG_FUSED_LOSS='0'), ('ppo', 'internal'), 'fused_minibatch or ppo_loss_kernel or graph_step or ppo_minibatch'),
 }
 _CHILD = {}
 
@@ -144,6 +148,11 @@ def test_round5_forced_large_batch_kernels_vs_oracle(built_lib):
 
 def test_catmix_epilogue_vs_oracle(built_lib):
     _forced_child('catmix_epi')
+
+
+@pytest.mark.parametrize('variant', ['loss_in_fwd_tail', 'loss_own_launch'])
+def test_other_loss_placements(built_lib, variant):
+    _forced_child(variant)
 
 
 def test_other_channel_counts_vs_oracle(built_lib):
