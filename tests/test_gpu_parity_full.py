@@ -105,6 +105,14 @@ _FORCED = {
     # k_heads_fwd; 0: the loss as its own launch) against the same oracle / autograd comparisons the default placement runs
     'loss_in_fwd_tail': (dict(MG_FUSED_LOSS='2'), ('ppo', 'internal'), 'fused_minibatch or ppo_loss_kernel or graph_step or ppo_minibatch'),
     'loss_own_launch': (dict(MG_FUSED_LOSS='0'), ('ppo', 'internal'), 'fused_minibatch or ppo_loss_kernel or graph_step or ppo_minibatch'),
+    # [r6] SchNetAC's head chains as grouped GEMM / gather / scatter launches (internal.inc; the default up to 16 atoms is one
+    # launch per direction, int_heads_fused.inc -- canvas 20 of the default run already takes the staged form)
+    'int_heads_staged': (dict(MG_INT_HEADS_FUSED='0'), ('internal',),
+                         'outputs_and_gradients or graph_step or epoch_cache or small_canvases or device_minibatch'),
+    # ... and the one-launch form WITHOUT the weights requested at the top (k_int_heads_fwd / _bwd: the kernels of the shapes
+    # k_int_heads_*_pre do not take, forced on the default shapes)
+    'int_heads_plain': (dict(MG_INT_HEADS_FUSED='2'), ('internal',),
+                        'outputs_and_gradients or graph_step or epoch_cache or small_canvases or device_minibatch'),
 }
 _CHILD = {}
 
@@ -152,6 +160,11 @@ def test_catmix_epilogue_vs_oracle(built_lib):
 
 @pytest.mark.parametrize('variant', ['loss_in_fwd_tail', 'loss_own_launch'])
 def test_other_loss_placements(built_lib, variant):
+    _forced_child(variant)
+
+
+@pytest.mark.parametrize('variant', ['int_heads_staged', 'int_heads_plain'])
+def test_internal_agent_other_head_kernels_vs_oracle(built_lib, variant):
     _forced_child(variant)
 
 
