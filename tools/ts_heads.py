@@ -43,6 +43,7 @@ def main():
         print('  bwd 2->13->28->3 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((2, 13), (13, 28), (28, 3))])
         print('  bwd 9->14->15->10 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((9, 14), (14, 15), (15, 10))])
         print('  fwd us since kernel start: role0 (16) ->17,18,19,44', [round((ts[j] - ts[16]) / 100.0, 1) for j in (17, 18, 19, 44)], '| role1 45,20..23', [round((ts[j] - ts[16]) / 100.0, 1) for j in (45, 20, 21, 22, 23)], '| role2 49,24..27', [round((ts[j] - ts[16]) / 100.0, 1) for j in (49, 24, 25, 26, 27)])
+        print('  fwd role2 start: 49 -> 61 (loads, staging) -> 62 (barrier) -> 63 (cat rows, CG power) -> 24 us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((49, 61), (61, 62), (62, 63), (63, 24))])
         print('  fwd role2 so3: 26 -> 56 (setup) -> 57 (pass 0) -> 58 (passes) -> 27 (reductions) us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((26, 56), (56, 57), (57, 58), (58, 27))])
         print('  bwd role1 47,28,3,4,5,11,12,6,7,8,48 us since 0:', [round((ts[j] - ts[0]) / 100.0, 1) for j in (47, 28, 3, 4, 5, 11, 12, 6, 7, 8, 48)])
         print('  bwd role1 start: 47 -> 59 (staging + barrier) -> 60 (thread 0: drawn orientation) -> 28 (Lebedev passes) us', [round((ts[j] - ts[i]) / 100.0, 1) for i, j in ((47, 59), (59, 60), (60, 28))])
