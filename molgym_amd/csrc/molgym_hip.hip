@@ -475,13 +475,17 @@ static int cov_forward_impl(const mg_cov_cfg* c, const float* theta, const float
       if (fusedE && !smp && catmix_epilogue(w, P, k)) {  // the atom cat-mix as the kernel's epilogue (A[k + 1] zeroed by k_edge_fwd above)
         for (int l = 0; l < 5; ++l) { mx.mf[l] = w.atom[k][l].mf; mx.ldf[l] = w.atom[k][l].ldf; mx.out[l] = w.A[k + 1][l]; }
         mx.ldo = 2 * P.atom_cout[k]; mx.nout = P.atom_cout[k];
-        hipLaunchKernelGGL(k_catbuild_mfma<true>, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E,
+        hipLaunchKernelGGL((k_catbuild_mfma<true, false>), dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E,
                            w.Ecm[k], w.Y, cd, g_cgtab[cur_device()], TA, TE, mx);
         LAUNCH_CHECK();
         continue;
       }
-      hipLaunchKernelGGL(k_catbuild_mfma<false>, dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k], w.Y,
-                         cd, g_cgtab[cur_device()], TA, TE, mx);
+      if (cgm_chunked(TA * CH))
+        hipLaunchKernelGGL((k_catbuild_mfma<false, true>), dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k],
+                           w.Y, cd, g_cgtab[cur_device()], TA, TE, mx);
+      else
+        hipLaunchKernelGGL((k_catbuild_mfma<false, false>), dim3(cgm_grid_persist(TA * CH, 2)), dim3(64 * CGM_WAVES), 0, s, w.L, w.Acm[k], E, w.Ecm[k],
+                           w.Y, cd, g_cgtab[cur_device()], TA, TE, mx);
     }
     LAUNCH_CHECK();
     GemmG ga[5];

@@ -131,7 +131,11 @@ def _pmc_traffic(config, name):
     rec = _pmc_file(config)[1]
     if rec is None:
         return None
-    return rec.get(name, {}).get('hbm_bytes_per_launch')
+    if name in rec:
+        return rec[name].get('hbm_bytes_per_launch')
+    # the span names are the kernels' names without template arguments (k_catbuild_bwd_mfma<false> / <true>: one of them runs at a config)
+    hits = [v for k, v in rec.items() if k.startswith(name + '<') and isinstance(v, dict) and v.get('hbm_bytes_per_launch') is not None]
+    return hits[0]['hbm_bytes_per_launch'] if len(hits) == 1 else None
 
 
 def step_hbm(config, ms_per_step):
