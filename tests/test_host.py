@@ -135,6 +135,29 @@ def test_lebedev_table_integrates_harmonics_exactly():
     np.testing.assert_allclose(gram, np.eye(25), atol=2e-6)
 
 
+def test_lebedev_table_has_the_symmetries_the_heads_kernels_read_it_with():
+    """[r6] k_heads_fwd / k_heads_bwd fetch 26 of the table's 51 rows (heads_fused.inc: leb_fetch26 / leb_y) and take the m < 0
+    rows from the m > 0 rows: Y_l,-m = (-1)^m conj(Y_l,m) and Im Y_l,0 = 0 must hold EXACTLY in the float32 table, and point
+    g + NLEB/2 must be exactly -point g with the same weight (the antipodal pairing both kernels use)"""
+    tab = lebedev_table()
+    assert tab.dtype == np.float32 and tab.shape == (51, 1730)
+    for l in range(5):
+        q0 = l * l + l
+        assert np.all(tab[2 * q0 + 1] == 0.0)
+        for m in range(1, l + 1):
+            sg = np.float32(-1.0 if m & 1 else 1.0)
+            qp, qm = q0 + m, q0 - m
+            np.testing.assert_array_equal(tab[2 * qm], sg * tab[2 * qp])
+            np.testing.assert_array_equal(tab[2 * qm + 1], -sg * tab[2 * qp + 1])
+    h = 1730 // 2
+    np.testing.assert_array_equal(tab[50, :h], tab[50, h:])
+    for q in range(25):  # Y_lm(-x) = (-1)^l Y_lm(x), exactly
+        l = int(np.floor(np.sqrt(q)))
+        sg = np.float32(-1.0 if l & 1 else 1.0)
+        np.testing.assert_array_equal(tab[2 * q, h:], sg * tab[2 * q, :h])
+        np.testing.assert_array_equal(tab[2 * q + 1, h:], sg * tab[2 * q + 1, :h])
+
+
 def test_product_path_never_imports_the_oracle():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
